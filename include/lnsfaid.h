@@ -1,0 +1,174 @@
+/*
+ * lnsfaid.h — C ABI of the MI355X-native batched LDPC decoder (50G-PON QC-LDPC,
+ * DecodeMethod 1 = OMS, 2 = LNS-FAID + DTBF, 5 = LNS-FAID + 2B1C).
+ *
+ * This is the drop-in boundary for the reference's decoder member functions
+ *   void CLDPC::Decode_OMS()        (reference CLDPC.h:148, CDecoder_OMS.cpp:13)
+ *   void CLDPC::Decode_FAID()       (reference CLDPC.h:149, CDecoder_FAID.cpp:176)
+ *   void CLDPC::Decode_FAID_2B1C()  (reference CLDPC.h:152, CDecoder_FAID_2B1C.cpp:96)
+ *   Statistic CLDPC::CalculateErrors(...) (reference CLDPC.h:169, CLDPC.cpp:4819)
+ * The reference has no FFI layer: inputs/outputs are the members `fixInput` /
+ * `decodedBits` of `class CLDPC` (CLDPC.h:125-126) and the configuration is read
+ * from Profile.txt (CTool.cpp:588-621) plus compile-time constants at the top of
+ * each decoder file.  The entry points below carry exactly that information as
+ * plain pointers and sizes.  INTEGRATION.md shows the CLDPC-side binding.
+ *
+ * Conventions: extern "C"; 0 = success, negative = error (lnsfaid_strerror);
+ * no exceptions and no exit() across the boundary; the caller owns every host
+ * buffer it passes, the context owns device buffers and its HIP stream.  One
+ * context per (host thread, GPU): thread-compatible, not thread-safe.
+ *
+ * Batches are consecutive GROUPS of 32 codewords.  The group is part of the
+ * contract: the reference decodes 32 codewords in lock-step and stops a group
+ * only when all 32 lanes are clean (CDecoder_FAID.cpp:616, :6782), which is
+ * observable in the hard decisions; this library reproduces it bit for bit.
+ */
+#ifndef LNSFAID_H
+#define LNSFAID_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LNSFAID_GROUP 32 /* codewords per group = Profile.txt noFrames = lanes of the reference's __m256i */
+
+/* error codes */
+#define LNSFAID_OK 0
+#define LNSFAID_E_INVAL (-1)    /* bad argument / unsupported configuration          */
+#define LNSFAID_E_CODE (-2)     /* H table is not the quasi-cyclic shape the kernels need */
+#define LNSFAID_E_NOMEM (-3)    /* host or device allocation failed                  */
+#define LNSFAID_E_HIP (-4)      /* a HIP runtime call failed (see lnsfaid_last_hip_error) */
+#define LNSFAID_E_NODEVICE (-5) /* no usable GPU / extension built without device code */
+#define LNSFAID_E_INTERNAL (-6)
+
+/*
+ * Code definition = the content of the reference's Constants_SSE.h
+ * (Constants/50GPON-dc-original/Constants_SSE.h:4-19 and :29-3102).
+ */
+typedef struct lnsfaid_code {
+    int32_t n_var;           /* _NoVar   17664 */
+    int32_t n_check;         /* _NoCheck 3072  */
+    int32_t n_edges;         /* _NoOnes  70400 */
+    int32_t z;               /* Profile.txt Z  256 (circulant size) */
+    int32_t puncture_tail;   /* number of tail VNs whose channel LLR is forced to 0
+                                (CDecoder_FAID.cpp:253-255: 384) */
+    int32_t nb_degres;       /* NB_DEGRES: number of consecutive row-degree classes */
+    const int32_t* deg;      /* [nb_degres] DEG_k */
+    const int32_t* deg_rows; /* [nb_degres] DEG_k_COMPUTATIONS */
+    const uint16_t* pos_vn;  /* [n_edges] PosNoeudsVariable, row-major VN indices */
+} lnsfaid_code;
+
+/*
+ * Decoder configuration = Profile.txt run-time keys + the compile-time
+ * constants at the top of CDecoder_OMS.cpp / CDecoder_FAID.cpp /
+ * CDecoder_FAID_2B1C.cpp.  lnsfaid_cfg_default() fills in the reference's
+ * shipped values for a DecodeMethod.
+ */
+typedef struct lnsfaid_cfg {
+    int32_t decode_method;     /* Profile.txt DecodeMethod: 1, 2 or 5 (README.md:13) */
+    int32_t max_iteration;     /* Profile.txt MaxIteration (nb_iteration)           */
+    int32_t factor_1;          /* Profile.txt Factor_1 (selective offset, OMS)      */
+    int32_t factor_2;          /* Profile.txt Factor_2                              */
+    int32_t floor_err_count;   /* CDecoder_OMS.cpp:28 (100) / FAID :193 (0) / 2B1C :117 (50) */
+    int32_t floor_iter_thresh; /* CDecoder_OMS.cpp:29 (4)  / FAID :194 (-1) / 2B1C :118 (6) */
+    int32_t ef_elimination;    /* EF_ELIMINATION 0 (FAID :6) or 1 (2B1C :5)          */
+    int32_t max_bf_iter;       /* _maxBFiter 10 (CDecoder_FAID.cpp:208); 0 for OMS   */
+    int32_t bf_L0;             /* _L0 50 (FAID :168) / 100 (2B1C :88)                */
+    int32_t bf_L1;             /* _L1 0                                              */
+    int32_t bf_alpha;          /* _alpha 1                                           */
+    int32_t bf_delta;          /* _delta 1                                           */
+    int32_t regular_col_weight;/* REGULAR_COL_WEIGHT 3 (CTool.h:6)                   */
+    int32_t hard2_threshold;   /* 13 (CDecoder_FAID_2B1C.cpp:6130)                   */
+    /* V2C_map_it{1..6}_[weight class 3,6,11,other][min(|t|,7)] (CDecoder_FAID.cpp:12-49) */
+    int8_t v2c_map[6][4][8];
+    /* V2C_map_it{1..6}_ef (CDecoder_FAID.cpp:130-165) */
+    int8_t v2c_map_ef[6][4][8];
+} lnsfaid_cfg;
+
+/* per-group execution record (used for the algorithmic-byte accounting) */
+typedef struct lnsfaid_group_stats {
+    int32_t iterations;    /* I: layered iterations executed by the group            */
+    int32_t bf_iterations; /* J: bit-flipping iterations that reached the flip step  */
+} lnsfaid_group_stats;
+
+typedef struct lnsfaid_ctx lnsfaid_ctx;
+
+/* ---- code / configuration helpers (host only, no GPU needed) ---------------- */
+
+/* Number of edges / VNs / checks of the built-in 50G-PON mother code and its
+ * expansion into the Constants_SSE.h table format.  `pos_vn` must hold 70400
+ * entries.  Returns LNSFAID_OK. */
+int lnsfaid_code_50gpon(lnsfaid_code* code, uint16_t* pos_vn, int32_t* deg3, int32_t* deg_rows3);
+
+/* Fill `cfg` with the reference's shipped constants for DecodeMethod 1, 2 or 5. */
+int lnsfaid_cfg_default(lnsfaid_cfg* cfg, int32_t decode_method, int32_t max_iteration);
+
+/* ---- decoder context --------------------------------------------------------- */
+
+/* Replaces CLDPC::Initial (CLDPC.cpp:4772-4817): validates the code (must be
+ * quasi-cyclic with circulant size z and no repeated block column inside a
+ * block row), uploads the tables and allocates device state for up to
+ * `max_groups` groups on GPU `device`. */
+int lnsfaid_create(lnsfaid_ctx** ctx, const lnsfaid_code* code, const lnsfaid_cfg* cfg,
+                   int32_t device, size_t max_groups);
+void lnsfaid_destroy(lnsfaid_ctx* ctx);
+
+/* Change the run-time configuration (the reference re-reads Profile.txt on
+ * every Decode_* call, CDecoder_FAID.cpp:178-179). */
+int lnsfaid_set_cfg(lnsfaid_ctx* ctx, const lnsfaid_cfg* cfg);
+
+/* ---- the hot path ------------------------------------------------------------ */
+
+/*
+ * Replaces Decode_OMS / Decode_FAID / Decode_FAID_2B1C for n_groups groups.
+ *   fixInput    host, int8 in [-7,7], per group the reference layout
+ *               [32][K] information LLRs followed by [32][M] parity LLRs
+ *               (CLDPC.h:126, CDecoder_FAID.cpp:217-241); group g starts at
+ *               g * 32 * n_var.
+ *   decodedBits host, int8 0/1, per group [32][n_var] (CLDPC.h:125,
+ *               CDecoder_FAID.cpp:7102); group g starts at g * 32 * n_var.
+ *   stats       optional, [n_groups].
+ */
+int lnsfaid_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, size_t n_groups,
+                   int8_t* decodedBits, lnsfaid_group_stats* stats);
+
+/* Same with device-resident buffers (pointers valid on the context's GPU).
+ * Asynchronous on the context's stream except for the small per-launch
+ * progress read-back; returns after the batch is complete.  d_stats optional. */
+int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput, size_t n_groups,
+                          int8_t* d_decodedBits, lnsfaid_group_stats* d_stats);
+
+/*
+ * Replaces CLDPC::CalculateErrors (CLDPC.cpp:4842-4876) for n_groups groups:
+ * compares the first K bits of every decoded frame with inputBits
+ * ([32][K] per group, int8 0/1) and ADDS to
+ *   out[0] TestFrame, out[1] ErrorFrame, out[2] ErrorBits, out[3] LT3ErrBitFrame.
+ * inputBits == NULL means the all-zero codeword (FakeEncoder with the shipped
+ * CodeWord_sym, CLDPC.cpp:163 / Codeword.h:4).
+ */
+int lnsfaid_count_errors(lnsfaid_ctx* ctx, const int8_t* decodedBits, const int8_t* inputBits,
+                         size_t n_groups, uint64_t out[4]);
+int lnsfaid_count_errors_device(lnsfaid_ctx* ctx, const int8_t* d_decodedBits,
+                                const int8_t* d_inputBits, size_t n_groups, uint64_t out[4]);
+
+/* ---- measurement hooks ------------------------------------------------------- */
+
+/* Device time (HIP events on the context's stream) and launch count of the
+ * decode kernel accumulated since the last reset: out_ms = total kernel
+ * milliseconds, out_launches = number of kernel launches. */
+int lnsfaid_kernel_time(lnsfaid_ctx* ctx, double* out_ms, uint64_t* out_launches, int32_t reset);
+
+/* The HIP stream of the context as an opaque pointer (hipStream_t). */
+void* lnsfaid_stream(lnsfaid_ctx* ctx);
+
+const char* lnsfaid_strerror(int err);
+const char* lnsfaid_last_hip_error(void);
+const char* lnsfaid_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LNSFAID_H */

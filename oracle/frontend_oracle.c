@@ -1,0 +1,89 @@
+/*
+ * frontend_oracle.c — CPU restatement of the reference's signal chain in front of the decoder,
+ * for ONE worker thread, QPSK, InterleaveModType 1.  TEST INFRASTRUCTURE ONLY (same rule as
+ * lnsfaid_oracle.c).  It exists so that the oracle can be driven with exactly the LLR stream the
+ * reference's own run saw (seed table CSimulate.cpp:11-17), which is what lets the counters recorded
+ * in SURVEY.md §6 pin the oracle.
+ *
+ * Restated stages, in the order of CSimulate::Run (CSimulate.cpp:103-132):
+ *   FakeEncoder            CLDPC.cpp:163-207   every one of the 32 frames carries the same codeword
+ *   BeforeModulationInterleaver, InterleaveModType 1   CModulate.cpp:95-148   -> identity per frame
+ *   Modulation, QPSK       CModulate.cpp:216-264, table_qpsk CModulate.cpp:4
+ *   AWGNChannel            CChannel.cpp:71-97   Wichmann-Hill triple + Box-Muller
+ *   Demodulation, QPSK     CModulate.cpp:273-281   LLR = (real, imag)
+ *   AfterDeModulationDeInterleaver   CModulate.cpp:152-212   -> [32][K] then [32][M]
+ *   float2LimitChar_4bit   CLDPC.cpp:4524-4582
+ */
+#include "lnsfaid_oracle.h"
+
+#include <math.h>
+
+void lnsfaid_frontend_seed(lnsfaid_frontend* fe, int seed)
+{
+    fe->IX = fe->IY = fe->IZ = (unsigned long)seed; /* CChannel.cpp:121 */
+}
+
+float lnsfaid_frontend_sigma(float eb_n0_db, int mod_type, double rate)
+{
+    /* CSimulate.cpp:69-74; snr is a float member, the arithmetic is double */
+    float snr = eb_n0_db;
+    if (mod_type == 1) return (float)(1.0 / sqrt(2.0 * rate * mod_type * pow(10.0, 0.1 * snr)));
+    return (float)(1.0 / sqrt(rate * mod_type * pow(10.0, 0.1 * snr)));
+}
+
+/* CChannel::Random_Uniform (CChannel.cpp:71-80): float arithmetic throughout */
+static float random_uniform(lnsfaid_frontend* rs)
+{
+    float temp = 0.0;
+    rs->IX = (rs->IX * 249) % 61967;
+    rs->IY = (rs->IY * 251) % 63443;
+    rs->IZ = (rs->IZ * 252) % 63599;
+    temp = (((float)rs->IX) / ((float)61967)) + (((float)rs->IY) / ((float)63443)) + (((float)rs->IZ) / ((float)63599));
+    temp -= (int)temp;
+    return temp;
+}
+
+/* CChannel::Random_Norm (CChannel.cpp:82-89): double arithmetic, result rounded to float */
+static float random_norm(double sigma, lnsfaid_frontend* rs)
+{
+    float u1, u2, u;
+    u1 = random_uniform(rs);
+    u2 = random_uniform(rs);
+    u = sigma * cos(2 * 3.1415926535897932384626433832795 * u2) * sqrt(-2.0 * log(1.0 - u1));
+    return u;
+}
+
+/* float2LimitChar_4bit (CLDPC.cpp:4553-4573): float multiply, truncate toward zero (cvttps2dq),
+ * saturating packs to int8, clamp to [-7, 7]. */
+static int8_t quantise_4bit(float x, float scale)
+{
+    float y = x * scale;
+    int q;
+    if (!(y > -2147483648.0f && y < 2147483648.0f)) q = (int)0x80000000; /* cvttps2dq "integer indefinite" */
+    else q = (int)y;
+    if (q > 127) q = 127;   /* packs_epi32 + packs_epi16 */
+    if (q < -128) q = -128;
+    if (q > 7) q = 7;
+    if (q < -7) q = -7;
+    return (int8_t)q;
+}
+
+void lnsfaid_frontend_qpsk_group(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* codeword, float sigma,
+                                 float scale, int8_t* fixInput)
+{
+    static const float table_qpsk[2] = { -0.707107f, 0.707107f }; /* CModulate.cpp:4 */
+    const int K = n_var - n_check;
+    /* AWGNChannel(modulate->ModSeq, sigma / sqrt(2)) (CSimulate.cpp:126): float / double -> double,
+     * narrowed to the float parameter of AWGNChannel, widened again for Random_Norm(double). */
+    const float sigma_ch = (float)(sigma / sqrt(2));
+    /* bit k of frame m sits at m*n_var + k in InterLeaveSeq; symbol i carries bits 2i (real), 2i+1 (imag)
+     * (CModulate.cpp:253-259 with half_sym = 1); AWGNChannel draws real then imag (CChannel.cpp:94-95). */
+    for (int m = 0; m < 32; ++m)
+        for (int k = 0; k < n_var; ++k) {
+            int bit = codeword ? codeword[k] : 0;
+            float rx = random_norm(sigma_ch, fe) + table_qpsk[bit];
+            int8_t q = quantise_4bit(rx, scale);
+            if (k < K) fixInput[(size_t)m * K + k] = q;
+            else fixInput[(size_t)32 * K + (size_t)m * n_check + (k - K)] = q;
+        }
+}

@@ -1,0 +1,452 @@
+/*
+ * lnsfaid_oracle.c — CPU restatement of the reference's batched LDPC decoders.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (the HIP library, the host driver) may
+ * include, link or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, as the checker / the reported CPU baseline.
+ *
+ * What it restates (plain C, one function per reference stage, group of 32 lanes in lock-step,
+ * every reference SIMD operation rewritten as a 32-lane scalar loop with the same int8
+ * saturation semantics):
+ *   - Decode_OMS        reference CDecoder_OMS.cpp:13-2998      (DecodeMethod 1)
+ *   - Decode_FAID       reference CDecoder_FAID.cpp:176-7135    (DecodeMethod 2, FAID + DTBF)
+ *   - Decode_FAID_2B1C  reference CDecoder_FAID_2B1C.cpp:96-6866 (DecodeMethod 5)
+ *   - CalculateErrors   reference CLDPC.cpp:4842-4876
+ * The reference unrolls its row loop once per degree class (DEG_1..DEG_3); the three copies are
+ * textually identical up to the degree (checked by diff), so one generic row loop is used here.
+ *
+ * Parity pinning: the reference cannot be built in this image (CLDPC.h:7 includes Intel MKL's
+ * mkl.h, which the image lacks, and stand-in headers are not allowed), and it ships no tests or
+ * golden vectors.  The oracle is pinned by (a) the reference's one known-answer fixture, the valid
+ * codeword in Codeword.h:7-460, (b) the SHA-256 of PosNoeudsVariable, and (c) the error counters the
+ * reference itself produced in this container during the survey (SURVEY.md §6 / BASELINE.md §2:
+ * DecodeMethod x Eb/N0 x {frame errors, bit errors} for seed 101), which tests/test_oracle_anchor.py
+ * reproduces through oracle/frontend_oracle.c.  See DESIGN.md "Oracle".
+ */
+#include "lnsfaid_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- the reference's SIMD vocabulary (CLDPC.h:21-96) as 32-lane scalar loops ------------------ */
+
+#define L 32
+typedef struct { int8_t b[L]; } v32; /* TYPE = __m256i of 32 int8 lanes (CLDPC.h:21) */
+typedef uint32_t m32;                /* __mmask32                                    */
+
+static inline int8_t sat8(int x) { return (int8_t)(x > 127 ? 127 : (x < -128 ? -128 : x)); }
+
+static inline v32 v_set1(int a) { v32 r; for (int l = 0; l < L; ++l) r.b[l] = (int8_t)a; return r; }
+/* VECTOR_ADD / VECTOR_SUB: _mm256_adds_epi8 / _mm256_subs_epi8 (CLDPC.h:26-27) */
+static inline v32 v_adds(v32 a, v32 b) { v32 r; for (int l = 0; l < L; ++l) r.b[l] = sat8(a.b[l] + b.b[l]); return r; }
+static inline v32 v_subs(v32 a, v32 b) { v32 r; for (int l = 0; l < L; ++l) r.b[l] = sat8(a.b[l] - b.b[l]); return r; }
+/* VECTOR_ABS: _mm256_abs_epi8 (abs(-128) stays -128) */
+static inline v32 v_abs(v32 a) { v32 r; for (int l = 0; l < L; ++l) r.b[l] = (int8_t)(a.b[l] < 0 ? (uint8_t)(-a.b[l]) : a.b[l]); return r; }
+static inline v32 v_max(v32 a, v32 b) { v32 r; for (int l = 0; l < L; ++l) r.b[l] = a.b[l] > b.b[l] ? a.b[l] : b.b[l]; return r; }
+static inline v32 v_min(v32 a, v32 b) { v32 r; for (int l = 0; l < L; ++l) r.b[l] = a.b[l] < b.b[l] ? a.b[l] : b.b[l]; return r; }
+static inline v32 v_xor(v32 a, v32 b) { v32 r; for (int l = 0; l < L; ++l) r.b[l] = (int8_t)(a.b[l] ^ b.b[l]); return r; }
+static inline v32 v_and(v32 a, v32 b) { v32 r; for (int l = 0; l < L; ++l) r.b[l] = (int8_t)(a.b[l] & b.b[l]); return r; }
+/* VECTOR_SIGN / VECTOR_invSIGN2: _mm256_sign_epi8(a, b) (CLDPC.h:36-53) */
+static inline v32 v_sign(v32 a, v32 b)
+{
+    v32 r;
+    for (int l = 0; l < L; ++l) r.b[l] = (int8_t)(b.b[l] < 0 ? (uint8_t)(-a.b[l]) : (b.b[l] == 0 ? 0 : a.b[l]));
+    return r;
+}
+/* signed compares into a mask (CLDPC.h:77-84) */
+static inline m32 m_gt(v32 a, v32 b) { m32 m = 0; for (int l = 0; l < L; ++l) m |= (m32)(a.b[l] > b.b[l]) << l; return m; }
+static inline m32 m_ge(v32 a, v32 b) { m32 m = 0; for (int l = 0; l < L; ++l) m |= (m32)(a.b[l] >= b.b[l]) << l; return m; }
+static inline m32 m_lt(v32 a, v32 b) { m32 m = 0; for (int l = 0; l < L; ++l) m |= (m32)(a.b[l] < b.b[l]) << l; return m; }
+static inline m32 m_le(v32 a, v32 b) { m32 m = 0; for (int l = 0; l < L; ++l) m |= (m32)(a.b[l] <= b.b[l]) << l; return m; }
+static inline m32 m_eq(v32 a, v32 b) { m32 m = 0; for (int l = 0; l < L; ++l) m |= (m32)(a.b[l] == b.b[l]) << l; return m; }
+/* unsigned compares (CLDPC.h:91-92) */
+static inline m32 m_gtu(v32 a, v32 b) { m32 m = 0; for (int l = 0; l < L; ++l) m |= (m32)((uint8_t)a.b[l] > (uint8_t)b.b[l]) << l; return m; }
+static inline m32 m_ltu(v32 a, v32 b) { m32 m = 0; for (int l = 0; l < L; ++l) m |= (m32)((uint8_t)a.b[l] < (uint8_t)b.b[l]) << l; return m; }
+/* VECTOR_ADD_MASK / VECTOR_SUB_MASK: _mm256_mask_adds_epi8(a, m, a, b) (CLDPC.h:82-83) */
+static inline v32 v_adds_mask(m32 m, v32 a, v32 b) { v32 r; for (int l = 0; l < L; ++l) r.b[l] = (m >> l) & 1 ? sat8(a.b[l] + b.b[l]) : a.b[l]; return r; }
+static inline v32 v_subs_mask(m32 m, v32 a, v32 b) { v32 r; for (int l = 0; l < L; ++l) r.b[l] = (m >> l) & 1 ? sat8(a.b[l] - b.b[l]) : a.b[l]; return r; }
+/* VECTOR_ADDU_MASK: _mm256_mask_adds_epu8 (CLDPC.h:93) */
+static inline v32 v_addu_mask(m32 m, v32 a, v32 b)
+{
+    v32 r;
+    for (int l = 0; l < L; ++l) {
+        int s = (uint8_t)a.b[l] + (uint8_t)b.b[l];
+        r.b[l] = (m >> l) & 1 ? (int8_t)(uint8_t)(s > 255 ? 255 : s) : a.b[l];
+    }
+    return r;
+}
+/* VECTOR_MOV_MASK(src, m, a): lanes with m take a, others src (CLDPC.h:96) */
+static inline v32 v_mov_mask(v32 src, m32 m, v32 a) { v32 r; for (int l = 0; l < L; ++l) r.b[l] = (m >> l) & 1 ? a.b[l] : src.b[l]; return r; }
+
+/* ---- weight class used to index V2C_map_*[4][8] (CDecoder_FAID.cpp:692-705) ------------------- */
+static inline int weight_class(int w) { return w == 3 ? 0 : (w == 6 ? 1 : (w == 11 ? 2 : 3)); }
+
+struct lnsfaid_oracle {
+    lnsfaid_code code;
+    lnsfaid_cfg cfg;
+    uint16_t* pos_vn;   /* PosNoeudsVariable                                   */
+    int32_t* row_deg;   /* degree of every check row (DEG_k by class)          */
+    int8_t* vn_weight;  /* VN_weight_ (CLDPC.cpp:4998-5003), zero-initialised   */
+    v32* var_nodes;     /* En,  [n_var]   (CLDPC.h:121)                        */
+    v32* var_msgs;      /* Lmn, [n_edges] (CLDPC.h:123)                        */
+    m32* checksum;      /* l_checksum_[_NoCheck]                               */
+    v32* flip_vote;     /* [n_var]                                             */
+    m32 *hard_llr, *hard2_llr, *hard_ch, *flip_record; /* [n_var] each        */
+};
+
+int lnsfaid_oracle_create(lnsfaid_oracle** out, const lnsfaid_code* code, const lnsfaid_cfg* cfg)
+{
+    if (!out || !code || !cfg || !code->pos_vn) return LNSFAID_E_INVAL;
+    if (cfg->decode_method != 1 && cfg->decode_method != 2 && cfg->decode_method != 5) return LNSFAID_E_INVAL;
+    lnsfaid_oracle* o = (lnsfaid_oracle*)calloc(1, sizeof(*o));
+    if (!o) return LNSFAID_E_NOMEM;
+    o->code = *code;
+    o->cfg = *cfg;
+    size_t E = (size_t)code->n_edges, N = (size_t)code->n_var, M = (size_t)code->n_check;
+    o->pos_vn = (uint16_t*)malloc(E * sizeof(uint16_t));
+    o->row_deg = (int32_t*)malloc(M * sizeof(int32_t));
+    o->vn_weight = (int8_t*)calloc(N, 1);
+    o->var_nodes = (v32*)malloc(N * sizeof(v32));
+    o->var_msgs = (v32*)malloc(E * sizeof(v32));
+    o->checksum = (m32*)malloc(M * sizeof(m32));
+    o->flip_vote = (v32*)malloc(N * sizeof(v32));
+    o->hard_llr = (m32*)malloc(N * sizeof(m32));
+    o->hard2_llr = (m32*)malloc(N * sizeof(m32));
+    o->hard_ch = (m32*)malloc(N * sizeof(m32));
+    o->flip_record = (m32*)malloc(N * sizeof(m32));
+    if (!o->pos_vn || !o->row_deg || !o->vn_weight || !o->var_nodes || !o->var_msgs || !o->checksum || !o->flip_vote
+        || !o->hard_llr || !o->hard2_llr || !o->hard_ch || !o->flip_record) {
+        lnsfaid_oracle_destroy(o);
+        return LNSFAID_E_NOMEM;
+    }
+    memcpy(o->pos_vn, code->pos_vn, E * sizeof(uint16_t));
+    o->code.pos_vn = o->pos_vn;
+    size_t r = 0, e = 0;
+    for (int k = 0; k < code->nb_degres; ++k)
+        for (int i = 0; i < code->deg_rows[k]; ++i) {
+            if (r >= M || code->deg[k] < 1 || code->deg[k] > 64 /* MAX_DEG */) { lnsfaid_oracle_destroy(o); return LNSFAID_E_CODE; }
+            o->row_deg[r++] = code->deg[k];
+            e += (size_t)code->deg[k];
+        }
+    if (r != M || e != E) { lnsfaid_oracle_destroy(o); return LNSFAID_E_CODE; }
+    /* VN_weight_count (CLDPC.cpp:4998-5003) */
+    for (size_t i = 0; i < E; ++i) {
+        if (o->pos_vn[i] >= N) { lnsfaid_oracle_destroy(o); return LNSFAID_E_CODE; }
+        o->vn_weight[o->pos_vn[i]]++;
+    }
+    *out = o;
+    return LNSFAID_OK;
+}
+
+void lnsfaid_oracle_destroy(lnsfaid_oracle* o)
+{
+    if (!o) return;
+    free(o->pos_vn); free(o->row_deg); free(o->vn_weight); free(o->var_nodes); free(o->var_msgs);
+    free(o->checksum); free(o->flip_vote); free(o->hard_llr); free(o->hard2_llr); free(o->hard_ch);
+    free(o->flip_record);
+    free(o);
+}
+
+/* Input staging (CDecoder_FAID.cpp:211-255 = CDecoder_OMS.cpp:34-79): Lmn = 0, the two
+ * uchar_transpose_avx calls (exact [32][n] -> [n][32] byte transposes, CTool.cpp:9), tail erase. */
+static void stage_input(lnsfaid_oracle* o, const int8_t* fixInput)
+{
+    const int N = o->code.n_var, M = o->code.n_check, K = N - M;
+    memset(o->var_msgs, 0, (size_t)o->code.n_edges * sizeof(v32));
+    for (int v = 0; v < K; ++v)
+        for (int l = 0; l < L; ++l) o->var_nodes[v].b[l] = fixInput[(size_t)l * K + v];
+    const int8_t* pp = fixInput + (size_t)K * L;
+    for (int j = 0; j < M; ++j)
+        for (int l = 0; l < L; ++l) o->var_nodes[K + j].b[l] = pp[(size_t)l * M + j];
+    for (int i = 0; i < o->code.puncture_tail; ++i) o->var_nodes[N - 1 - i] = v_set1(0);
+}
+
+/* Syndrome / early-stop stage (CDecoder_FAID.cpp:291-343, CDecoder_OMS.cpp:102-323).
+ * Returns error_sum; fills o->checksum.  `unsigned_sum` selects VECTOR_ADDU_MASK (OMS) versus
+ * VECTOR_ADD_MASK (FAID, 2B1C). */
+static v32 syndrome_stage(lnsfaid_oracle* o, int unsigned_sum)
+{
+    const v32 zero = v_set1(0), ones = v_set1(1);
+    v32 error_sum = zero;
+    const uint16_t* pCN = o->pos_vn;
+    for (int r = 0; r < o->code.n_check; ++r) {
+        m32 mask_sum = 0;
+        for (int j = 0; j < o->row_deg[r]; ++j) mask_sum ^= m_gt(o->var_nodes[*pCN++], zero);
+        o->checksum[r] = mask_sum;
+        error_sum = unsigned_sum ? v_addu_mask(mask_sum, error_sum, ones) : v_adds_mask(mask_sum, error_sum, ones);
+    }
+    return error_sum;
+}
+
+/* selective offset of one minimum, OMS_MODE 1 (CDecoder_OMS.cpp:388-425) */
+static v32 oms_selective_offset(v32 x, int in_floor_window, m32 F, v32 factor_1, v32 factor_2)
+{
+    const v32 ones = v_set1(1);
+    if (in_floor_window) {
+        m32 k = F & m_lt(x, factor_2);
+        x = v_adds_mask(k, x, ones);
+        k = F & m_le(x, factor_1);
+        x = v_adds_mask(k, x, ones);
+        k = ~F & m_gt(x, factor_1);
+        x = v_subs_mask(k, x, ones);
+        k = ~F & m_ge(x, factor_2);
+        x = v_subs_mask(k, x, ones);
+    } else {
+        m32 k = m_gt(x, factor_1);
+        x = v_subs_mask(k, x, ones);
+        k = m_ge(x, factor_2);
+        x = v_subs_mask(k, x, ones);
+    }
+    return x;
+}
+
+#define MAX_DEG 64
+
+/* One layered iteration over all check rows, in table order (row r+1 sees the En written by row r).
+ * FAID / 2B1C: CDecoder_FAID.cpp:631-936 (and the identical DEG_2 / DEG_3 copies :944-1527);
+ * OMS: CDecoder_OMS.cpp:334-478 (and :486-743). */
+static void layered_iteration(lnsfaid_oracle* o, int nombre_iterations /* remaining after this one */, m32 l_m_error_sum)
+{
+    const lnsfaid_cfg* c = &o->cfg;
+    const int oms = (c->decode_method == 1);
+    const int SAT_POS_VAR = 31, SAT_NEG_VAR = -31, SAT_POS_MSG = 7; /* Constants_SSE.h:20-25 */
+    const v32 zero = v_set1(0);
+    const v32 min_var = v_set1(SAT_NEG_VAR), max_var = v_set1(SAT_POS_VAR), max_msg = v_set1(SAT_POS_MSG);
+    const v32 msign8 = v_set1((int8_t)0x80);
+    const v32 factor_1 = v_set1(c->factor_1), factor_2 = v_set1(c->factor_2);
+    const int it = c->max_iteration - nombre_iterations; /* nb_iteration - nombre_iterations, 1-based */
+    const int it_idx = (it >= 1 && it <= 5) ? it - 1 : 5;  /* switch at CDecoder_FAID.cpp:760-779 */
+    const int in_floor_window = (nombre_iterations <= c->floor_iter_thresh);
+
+    size_t e = 0;
+    for (int r = 0; r < o->code.n_check; ++r) {
+        const int deg = o->row_deg[r];
+        v32 tab_vContr[MAX_DEG], temp_vContr[MAX_DEG], _sign[MAX_DEG];
+        v32 sign = zero;
+        v32 min1 = v_set1(SAT_POS_VAR), min2 = min1;
+
+        for (int j = 0; j < deg; ++j) {
+            const int col = o->pos_vn[e + j];
+            v32 vNoeud = o->var_nodes[col];
+            v32 vMessg = o->var_msgs[e + j];
+            /* VECTOR_SUB_AND_SATURATE_VAR_8bits (CLDPC.h:65) */
+            v32 vContr = v_max(v_subs(vNoeud, vMessg), min_var);
+            if (oms) {
+                /* CDecoder_OMS.cpp:371-377: no upper clamp, plain sign bit, |t| clamped to 7 for the minima */
+                v32 cSign = v_and(vContr, msign8);
+                sign = v_xor(sign, cSign);
+                v32 vAbs = v_min(v_abs(vContr), max_msg);
+                tab_vContr[j] = vContr;
+                min2 = v_min(min2, v_max(min1, vAbs)); /* VECTOR_MIN_2 with the old min1 */
+                min1 = v_min(vAbs, min1);
+            } else {
+                vContr = v_min(vContr, max_var); /* CDecoder_FAID.cpp:672 */
+                /* FAID2_SIGN_BACKTRACK (CDecoder_FAID.cpp:682): a zero V2C takes the sign of En */
+                v32 cSign = v_and(v_adds_mask(m_eq(vContr, zero), vContr, vNoeud), msign8);
+                _sign[j] = cSign;
+                sign = v_xor(sign, cSign);
+                v32 vAbs = v_abs(vContr);
+                temp_vContr[j] = vContr;
+                const int idx1 = weight_class(o->vn_weight[col]);
+                /* step-by-step LUT mapping (CDecoder_FAID.cpp:706-852) */
+                v32 tmp = zero;
+                m32 mask_eef = 0;
+                if (c->ef_elimination >= 1)
+                    mask_eef = (in_floor_window ? 0xFFFFFFFFu : 0u) & l_m_error_sum & o->checksum[r];
+                for (int idx2 = 0; idx2 <= SAT_POS_MSG + 1; ++idx2) {
+                    /* idx2 == 8 is the overflow branch: |t| >= 8 maps through column 7 (:783) */
+                    m32 mask = idx2 <= SAT_POS_MSG ? m_eq(vAbs, v_set1(idx2)) : m_ge(vAbs, v_set1(SAT_POS_MSG + 1));
+                    const int colm = idx2 <= SAT_POS_MSG ? idx2 : SAT_POS_MSG;
+                    if (c->ef_elimination >= 1) {
+                        v32 tmp1 = v_adds_mask(mask_eef, zero, v_set1(c->v2c_map_ef[it_idx][idx1][colm]));
+                        v32 tmp2 = v_adds_mask(~mask_eef, zero, v_set1(c->v2c_map[it_idx][idx1][colm]));
+                        tmp = v_adds_mask(mask, tmp, tmp1);
+                        tmp = v_adds_mask(mask, tmp, tmp2);
+                    } else {
+                        tmp = v_adds_mask(mask, tmp, v_set1(c->v2c_map[it_idx][idx1][colm]));
+                    }
+                }
+                v32 vTemp = min1;
+                min1 = v_min(tmp, min1);
+                min2 = v_min(min2, v_max(vTemp, tmp));
+                tab_vContr[j] = tmp;
+            }
+        }
+
+        v32 cste_1, cste_2;
+        if (oms) {
+            /* OMS_MODE 1 (CDecoder_OMS.cpp:383-432) */
+            const m32 F = o->checksum[r] & l_m_error_sum;
+            v32 min1_offed = oms_selective_offset(min1, in_floor_window, F, factor_1, factor_2);
+            v32 min2_offed = oms_selective_offset(min2, in_floor_window, F, factor_1, factor_2);
+            cste_1 = v_min(min2_offed, max_msg);
+            cste_2 = v_min(min1_offed, max_msg);
+        } else {
+            /* OMS_MODE 0, offset 0 (CDecoder_FAID.cpp:864-866; 2B1C clamps min1/min2 first, :671-674) */
+            if (c->decode_method == 5) { min1 = v_min(min1, max_msg); min2 = v_min(min2, max_msg); }
+            cste_1 = v_min(v_subs(min2, v_set1(0)), max_msg);
+            cste_2 = v_min(v_subs(min1, v_set1(0)), max_msg);
+        }
+
+        /* sign ^= 0xC0 for odd degree, 0x40 for even (CDecoder_FAID.cpp:902-906) */
+        sign = v_xor(sign, v_set1((int8_t)((deg & 1) ? 0xC0 : 0x40)));
+
+        for (int j = 0; j < deg; ++j) {
+            v32 vAbs = v_abs(tab_vContr[j]);
+            m32 z = m_eq(vAbs, min1);
+            v32 vRes = v_mov_mask(cste_2, z, cste_1); /* (cste_1 & z) | (~z & cste_2) */
+            v32 vSig = v_xor(sign, oms ? v_and(tab_vContr[j], msign8) : _sign[j]);
+            v32 v2St = v_sign(vRes, vSig);
+            v32 base = oms ? tab_vContr[j] : temp_vContr[j];
+            /* VECTOR_ADD_AND_SATURATE_VAR_8bits then VECTOR_MIN(max_var) (CDecoder_FAID.cpp:918-920) */
+            v32 v2Sr = v_min(v_max(v_adds(base, v2St), min_var), max_var);
+            o->var_msgs[e + j] = v2St;
+            o->var_nodes[o->pos_vn[e + j]] = v2Sr;
+        }
+        e += (size_t)deg;
+    }
+}
+
+/* DTBF (CDecoder_FAID.cpp:6411-7093) and 2B1C (CDecoder_FAID_2B1C.cpp:6124-6824) post-processors.
+ * Returns the number of BF iterations that reached the flip step. */
+static int bit_flipping(lnsfaid_oracle* o)
+{
+    const lnsfaid_cfg* c = &o->cfg;
+    const int N = o->code.n_var;
+    const int two_bit = (c->decode_method == 5);
+    const v32 zero = v_set1(0), ones = v_set1(1);
+    const int W = c->regular_col_weight;
+    for (int i = 0; i < N; ++i) {
+        o->hard_llr[i] = m_gt(o->var_nodes[i], zero);
+        o->hard2_llr[i] = two_bit ? (m_ge(o->var_nodes[i], v_set1(c->hard2_threshold)) | m_le(o->var_nodes[i], v_set1(-c->hard2_threshold))) : 0;
+        o->hard_ch[i] = o->hard_llr[i];
+        o->flip_record[i] = 0;
+    }
+    int BFiter = 0;
+    m32 t = 0xFFFFFFFFu;
+    v32 Th = v_set1(W), l0 = zero, l1 = zero;
+    const v32 L0 = v_set1(c->bf_L0), L1 = v_set1(c->bf_L1), alpha = v_set1(c->bf_alpha), delta = v_set1(c->bf_delta);
+
+    while (BFiter < c->max_bf_iter) {
+        for (int i = 0; i < N; ++i) o->flip_vote[i] = zero;
+        v32 error_sum = zero;
+        const uint16_t* pCN = o->pos_vn;
+        const uint16_t* pCN2 = o->pos_vn;
+        for (int r = 0; r < o->code.n_check; ++r) {
+            m32 mask_sum = 0;
+            for (int j = 0; j < o->row_deg[r]; ++j) mask_sum ^= o->hard_llr[*pCN++];
+            o->checksum[r] = mask_sum;
+            error_sum = v_addu_mask(mask_sum, error_sum, ones);
+            for (int j = 0; j < o->row_deg[r]; ++j) {
+                o->flip_vote[*pCN2] = v_addu_mask(mask_sum, o->flip_vote[*pCN2], ones);
+                pCN2++;
+            }
+        }
+        if (m_gtu(error_sum, zero) == 0) break; /* all 32 frames are clean (:6782) */
+
+        /* threshold state machine (CDecoder_FAID.cpp:6787-6799) */
+        Th = v_subs_mask(~t, Th, delta);
+        m32 max_Th = t & m_lt(l0, L0);
+        Th = v_mov_mask(Th, max_Th, v_set1(W + c->bf_alpha));
+        l0 = v_adds_mask(max_Th, l0, ones);
+        m32 submax_Th = t & ~max_Th & m_lt(l1, L1);
+        Th = v_mov_mask(Th, submax_Th, v_set1(W + c->bf_alpha - c->bf_delta));
+        l1 = v_adds_mask(submax_Th, l1, ones);
+        m32 ssubmax_Th = t & ~max_Th & ~submax_Th;
+        Th = v_mov_mask(Th, ssubmax_Th, v_set1(W + c->bf_alpha - 2 * c->bf_delta));
+        Th = v_max(Th, ones);
+        t = 0;
+
+        /* flip decision, only on VNs of column weight W (CDecoder_FAID.cpp:6806-6845) */
+        pCN2 = o->pos_vn;
+        for (int k = 0; k < o->code.n_edges; ++k, ++pCN2) {
+            if (o->vn_weight[*pCN2] == W) {
+                m32 mask_flip = m_ge(v_adds_mask(o->hard_llr[*pCN2] ^ o->hard_ch[*pCN2], o->flip_vote[*pCN2], alpha), Th);
+                o->flip_record[*pCN2] = mask_flip;
+                t |= mask_flip;
+            }
+        }
+        if (!two_bit) {
+            for (int i = 0; i < N; ++i) o->hard_llr[i] ^= o->flip_record[i]; /* :7084-7086 */
+        } else {
+            /* 2-bit / 1-cycle flip (CDecoder_FAID_2B1C.cpp:6801-6814) */
+            m32 big = m_ge(Th, v_set1(W));
+            for (int i = 0; i < N; ++i) {
+                m32 xor3 = big & o->flip_record[i];
+                o->hard_llr[i] ^= xor3;
+                o->hard2_llr[i] ^= xor3;
+                o->hard_llr[i] ^= ~big & o->flip_record[i] & ~o->hard2_llr[i];
+                o->hard2_llr[i] ^= ~big & o->flip_record[i] & o->hard2_llr[i];
+            }
+        }
+        BFiter++;
+    }
+    /* write back +1 / -1 (CDecoder_FAID.cpp:7091-7093) */
+    for (int i = 0; i < N; ++i) o->var_nodes[i] = v_mov_mask(v_set1(-1), o->hard_llr[i], ones);
+    return BFiter;
+}
+
+/* One reference Decode_*() call = one group of 32 frames. */
+static void decode_group(lnsfaid_oracle* o, const int8_t* fixInput, int8_t* decodedBits, lnsfaid_group_stats* st)
+{
+    const lnsfaid_cfg* c = &o->cfg;
+    const int oms = (c->decode_method == 1);
+    const v32 zero = v_set1(0);
+    stage_input(o, fixInput);
+
+    int executed = 0;
+    int nombre_iterations = c->max_iteration;
+    while (nombre_iterations--) {
+        v32 error_sum = syndrome_stage(o, oms);
+        m32 l_m_error_sum;
+        if (oms) {
+            if (m_gtu(error_sum, zero) == 0) break;                           /* CDecoder_OMS.cpp:325 */
+            l_m_error_sum = m_ltu(error_sum, v_set1((uint8_t)c->floor_err_count)); /* :328 (uint8_t) */
+        } else {
+            if (m_gt(error_sum, zero) == 0) break;                            /* CDecoder_FAID.cpp:616 */
+            l_m_error_sum = m_lt(error_sum, v_set1((int8_t)c->floor_err_count));   /* :619 (int8_t)  */
+        }
+        layered_iteration(o, nombre_iterations, l_m_error_sum);
+        executed++;
+    }
+    int bf = 0;
+    if (!oms) bf = bit_flipping(o);
+    /* uchar_itranspose_avx with LOAD_AND_DECIDE (CTool.cpp:291-575): out[l*N+v] = En[v][l] > 0 */
+    const int N = o->code.n_var;
+    for (int v = 0; v < N; ++v)
+        for (int l = 0; l < L; ++l) decodedBits[(size_t)l * N + v] = (int8_t)(o->var_nodes[v].b[l] > 0);
+    if (st) { st->iterations = executed; st->bf_iterations = bf; }
+}
+
+int lnsfaid_oracle_decode(lnsfaid_oracle* o, const int8_t* fixInput, size_t n_groups, int8_t* decodedBits,
+                          lnsfaid_group_stats* stats)
+{
+    if (!o || (n_groups && (!fixInput || !decodedBits))) return LNSFAID_E_INVAL;
+    const size_t stride = (size_t)L * (size_t)o->code.n_var;
+    for (size_t g = 0; g < n_groups; ++g)
+        decode_group(o, fixInput + g * stride, decodedBits + g * stride, stats ? stats + g : NULL);
+    return LNSFAID_OK;
+}
+
+/* CalculateErrors (CLDPC.cpp:4842-4876): information bits only. */
+int lnsfaid_oracle_count_errors(const lnsfaid_code* code, const int8_t* decodedBits, const int8_t* inputBits,
+                                size_t n_groups, uint64_t out[4])
+{
+    if (!code || !out || (n_groups && !decodedBits)) return LNSFAID_E_INVAL;
+    const size_t N = (size_t)code->n_var, K = N - (size_t)code->n_check;
+    for (size_t g = 0; g < n_groups; ++g)
+        for (size_t i = 0; i < L; ++i) {
+            unsigned long errorBits = 0;
+            for (size_t j = 0; j < K; ++j) {
+                int8_t ref = inputBits ? inputBits[(g * L + i) * K + j] : 0;
+                if (decodedBits[(g * L + i) * N + j] != ref) errorBits++;
+            }
+            out[0] += 1;
+            if (errorBits > 0) {
+                out[2] += errorBits;
+                out[1] += 1;
+                if (errorBits < 3) out[3] += 1;
+            }
+        }
+    return LNSFAID_OK;
+}

@@ -1,0 +1,43 @@
+/*
+ * lnsfaid_oracle.h — CPU oracle for the decode hot path.  TEST INFRASTRUCTURE ONLY (see the header
+ * of lnsfaid_oracle.c): never included or linked by the product path.
+ * Uses the product's public structs (include/lnsfaid.h) so both sides see identical inputs.
+ */
+#ifndef LNSFAID_ORACLE_H
+#define LNSFAID_ORACLE_H
+#include "lnsfaid.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lnsfaid_oracle lnsfaid_oracle;
+
+int lnsfaid_oracle_create(lnsfaid_oracle** out, const lnsfaid_code* code, const lnsfaid_cfg* cfg);
+void lnsfaid_oracle_destroy(lnsfaid_oracle* o);
+/* same buffers and layout as lnsfaid_decode() */
+int lnsfaid_oracle_decode(lnsfaid_oracle* o, const int8_t* fixInput, size_t n_groups, int8_t* decodedBits,
+                          lnsfaid_group_stats* stats);
+int lnsfaid_oracle_count_errors(const lnsfaid_code* code, const int8_t* decodedBits, const int8_t* inputBits,
+                                size_t n_groups, uint64_t out[4]);
+
+/* ---- front-end restatement (frontend_oracle.c): the reference's channel for one worker thread --- */
+typedef struct lnsfaid_frontend {
+    unsigned long IX, IY, IZ; /* Wichmann-Hill state, RandSeed (CChannel.h:15-20) */
+} lnsfaid_frontend;
+
+/* CChannel::Initial without CONTINUE_SEED (CChannel.cpp:121): IX = IY = IZ = seed */
+void lnsfaid_frontend_seed(lnsfaid_frontend* fe, int seed);
+/* sigma of CSimulate::Configure (CSimulate.cpp:69-74) for modulation order mod_type (1 BPSK, 2 QPSK) */
+float lnsfaid_frontend_sigma(float eb_n0_db, int mod_type, double rate);
+/* One pass of the loop body of CSimulate::Run (CSimulate.cpp:126-132) for QPSK, InterleaveModType 1,
+ * transmitted codeword `codeword` ([n_var] bits 0/1, NULL = all-zero, same for all 32 frames as
+ * FakeEncoder does): AWGNChannel(sigma/sqrt(2)) -> Demodulation -> AfterDeModulationDeInterleaver ->
+ * float2LimitChar_4bit.  Writes one group of fixInput ([32][K] then [32][M]). */
+void lnsfaid_frontend_qpsk_group(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* codeword, float sigma,
+                                 float scale, int8_t* fixInput);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

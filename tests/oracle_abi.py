@@ -1,0 +1,114 @@
+"""ctypes view of oracle/liblnsfaid_oracle.so (the CPU oracle: test infrastructure only)."""
+import ctypes as C
+import importlib.util
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "liblnsfaid_oracle.so")
+PKG_DIR = os.path.join(ROOT, "mod-interleaveavx_multithreads-faid_amd")
+
+
+def load_pyabi():
+    """The package directory name is not a Python identifier, so import its ctypes module by path."""
+    spec = importlib.util.spec_from_file_location("lnsfaid_pyabi", os.path.join(PKG_DIR, "pyabi.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+pyabi = load_pyabi()
+
+
+class Frontend(C.Structure):
+    _fields_ = [("IX", C.c_ulong), ("IY", C.c_ulong), ("IZ", C.c_ulong)]
+
+
+_SYMS = {
+    "lnsfaid_oracle_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(pyabi.Code), C.POINTER(pyabi.Cfg)]),
+    "lnsfaid_oracle_destroy": (None, [C.c_void_p]),
+    "lnsfaid_oracle_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "lnsfaid_oracle_count_errors": (C.c_int, [C.POINTER(pyabi.Code), C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "lnsfaid_frontend_seed": (None, [C.POINTER(Frontend), C.c_int]),
+    "lnsfaid_frontend_sigma": (C.c_float, [C.c_float, C.c_int, C.c_double]),
+    "lnsfaid_frontend_qpsk_group": (None, [C.POINTER(Frontend), C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_LIB):
+            subprocess.check_call(["make", "-C", ORACLE_DIR])
+        _lib = pyabi.bind(C.CDLL(ORACLE_LIB), _SYMS)
+    return _lib
+
+
+class Oracle:
+    def __init__(self, code50, cfg):
+        self.lib = load()
+        self.code50 = code50
+        self.h = C.c_void_p()
+        rc = self.lib.lnsfaid_oracle_create(C.byref(self.h), C.byref(code50.code), C.byref(cfg))
+        if rc != 0:
+            raise RuntimeError("lnsfaid_oracle_create failed: %d" % rc)
+
+    def decode(self, fix_input, n_groups):
+        N = self.code50.N
+        assert fix_input.dtype == np.int8 and fix_input.size == n_groups * 32 * N
+        fix_input = np.ascontiguousarray(fix_input)
+        out = np.empty(n_groups * 32 * N, dtype=np.int8)
+        stats = np.zeros((n_groups, 2), dtype=np.int32)
+        rc = self.lib.lnsfaid_oracle_decode(self.h, fix_input.ctypes.data, n_groups, out.ctypes.data, stats.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("lnsfaid_oracle_decode failed: %d" % rc)
+        return out, stats
+
+    def count_errors(self, decoded, input_bits, n_groups):
+        out = (C.c_uint64 * 4)()
+        ip = input_bits.ctypes.data if input_bits is not None else None
+        rc = self.lib.lnsfaid_oracle_count_errors(C.byref(self.code50.code), decoded.ctypes.data, ip, n_groups, out)
+        if rc != 0:
+            raise RuntimeError("lnsfaid_oracle_count_errors failed: %d" % rc)
+        return list(out)
+
+    def close(self):
+        if self.h:
+            self.lib.lnsfaid_oracle_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ReferenceChannel:
+    """The reference's per-thread QPSK/AWGN front-end (oracle/frontend_oracle.c)."""
+
+    RATE = 0.8444444  # m_Rate, reference CLDPC.cpp:4780
+
+    def __init__(self, code50, seed=101, scale=13.0):
+        self.lib = load()
+        self.code50 = code50
+        self.fe = Frontend()
+        self.scale = scale
+        self.lib.lnsfaid_frontend_seed(C.byref(self.fe), seed)
+
+    def groups(self, eb_n0_db, n_groups, codeword=None):
+        N, M = self.code50.N, self.code50.M
+        sigma = self.lib.lnsfaid_frontend_sigma(eb_n0_db, 2, self.RATE)
+        out = np.empty((n_groups, 32 * N), dtype=np.int8)
+        cw = None
+        if codeword is not None:
+            codeword = np.ascontiguousarray(codeword, dtype=np.int8)
+            cw = codeword.ctypes.data
+        for g in range(n_groups):
+            self.lib.lnsfaid_frontend_qpsk_group(C.byref(self.fe), N, M, cw, sigma, self.scale, out[g].ctypes.data)
+        return out.reshape(-1)
