@@ -1,0 +1,377 @@
+/*
+ * lnsfaid_capi.hip — host side of the C ABI declared in include/lnsfaid.h.
+ *
+ * Owns the context (device tables, per-codeword state in HBM, one HIP stream, events) and drives the
+ * relaunch loop described at the top of lnsfaid_kernels.hip.  There is no CPU decode path in this
+ * library: without a GPU lnsfaid_create() fails with LNSFAID_E_NODEVICE.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "lnsfaid_device.h"
+
+extern "C" hipError_t lf_launch_decode(int method, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t lf_launch_count_errors(const int8_t* decoded, const int8_t* input_bits, int n_var, int k_info,
+                                             size_t n_cw, unsigned long long* out, hipStream_t stream);
+
+static thread_local char g_hip_err[256] = "";
+
+static int hip_fail(hipError_t e, const char* what)
+{
+    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
+    return LNSFAID_E_HIP;
+}
+#define HIP_TRY(call)                                      \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);  \
+    } while (0)
+
+struct lnsfaid_ctx {
+    int device = 0;
+    size_t max_groups = 0;
+    LfDevCode hcode;
+    LfDevCfg hcfg;
+    int n_var = 0, n_check = 0, k_info = 0;
+    size_t lds_bytes = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    LfDevCode* d_code = nullptr;
+    LfDevCfg* d_cfg = nullptr;
+    int8_t* d_en = nullptr;
+    uint2* d_rows = nullptr;
+    uint32_t* d_bits = nullptr;
+    LfLaneState* d_lane = nullptr;
+    int32_t* d_status[2] = { nullptr, nullptr };
+    uint32_t* d_remaining = nullptr;
+    unsigned long long* d_counters = nullptr;
+    uint32_t* h_remaining = nullptr;          /* pinned */
+    unsigned long long* h_counters = nullptr; /* pinned */
+    /* staging for the host-pointer entry points */
+    int8_t* d_io_in = nullptr;
+    int8_t* d_io_out = nullptr;
+    lnsfaid_group_stats* d_io_stats = nullptr;
+    double kernel_ms = 0.0;
+    uint64_t kernel_launches = 0;
+};
+
+/* ---- code analysis: PosNoeudsVariable -> circulants ------------------------------------------------- */
+static int weight_class(int w) { return w == 3 ? 0 : (w == 6 ? 1 : (w == 11 ? 2 : 3)); } /* CDecoder_FAID.cpp:692-705 */
+
+static int build_code(const lnsfaid_code* code, LfDevCode* out)
+{
+    memset(out, 0, sizeof(*out));
+    if (!code || !code->pos_vn || !code->deg || !code->deg_rows) return LNSFAID_E_INVAL;
+    const int Z = code->z, N = code->n_var, M = code->n_check, E = code->n_edges;
+    if (Z != LF_Z) return LNSFAID_E_CODE; /* kernels map one circulant row to one of 256 threads */
+    if (N <= 0 || M <= 0 || N % Z || M % Z || M >= N) return LNSFAID_E_CODE;
+    const int nbr = M / Z, nbc = N / Z, K = N - M;
+    if (nbr > LF_MAX_BR || nbc > LF_MAX_BC) return LNSFAID_E_CODE;
+    if (K % 4 || M % 4 || N % 64) return LNSFAID_E_CODE; /* dword staging, 64-wide ballots over VNs */
+    if (code->puncture_tail < 0 || code->puncture_tail > N) return LNSFAID_E_CODE;
+    /* degree of each check row from the DEG_k / DEG_k_COMPUTATIONS classes */
+    std::vector<int> row_deg;
+    row_deg.reserve(M);
+    long e_total = 0;
+    for (int k = 0; k < code->nb_degres; ++k) {
+        if (code->deg_rows[k] < 0 || code->deg[k] < 2 || code->deg[k] > LF_MAX_DEG) return LNSFAID_E_CODE;
+        for (int i = 0; i < code->deg_rows[k]; ++i) { row_deg.push_back(code->deg[k]); e_total += code->deg[k]; }
+    }
+    if ((int)row_deg.size() != M || e_total != E) return LNSFAID_E_CODE;
+
+    size_t e = 0;
+    for (int br = 0; br < nbr; ++br) {
+        const int deg = row_deg[(size_t)br * Z];
+        out->deg[br] = deg;
+        const uint16_t* row0 = code->pos_vn + e;
+        int prev_cb = -1;
+        for (int j = 0; j < deg; ++j) {
+            const int cb = row0[j] / Z, sh = row0[j] % Z;
+            if (row0[j] >= N || cb <= prev_cb) return LNSFAID_E_CODE; /* ascending, no block column twice */
+            prev_cb = cb;
+            out->circ[br][j] = (uint32_t)cb | ((uint32_t)sh << 8);
+            if (out->col_weight[cb] >= LF_MAX_COLW) return LNSFAID_E_CODE;
+            out->colcirc[cb][out->col_weight[cb]++] = (uint32_t)br | ((uint32_t)sh << 8);
+        }
+        for (int i = 0; i < Z; ++i) {
+            if (row_deg[(size_t)br * Z + i] != deg) return LNSFAID_E_CODE;
+            for (int j = 0; j < deg; ++j) {
+                const uint32_t ci = out->circ[br][j];
+                const int want = (int)(ci & 0xff) * Z + (int)((((ci >> 8) & 0xff) + (uint32_t)i) % (uint32_t)Z);
+                if (code->pos_vn[e + (size_t)i * deg + j] != want) return LNSFAID_E_CODE; /* not quasi-cyclic */
+            }
+        }
+        e += (size_t)deg * Z;
+    }
+    for (int br = 0; br < nbr; ++br)
+        for (int j = 0; j < out->deg[br]; ++j)
+            out->circ[br][j] |= (uint32_t)weight_class(out->col_weight[out->circ[br][j] & 0xff]) << 16;
+    out->n_var = N; out->n_check = M; out->k_info = K; out->nbr = nbr; out->nbc = nbc;
+    out->puncture_tail = code->puncture_tail;
+    out->n_words = N / 32; out->p_words = M / 32;
+    return LNSFAID_OK;
+}
+
+static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
+{
+    if (!cfg) return LNSFAID_E_INVAL;
+    if (cfg->decode_method != 1 && cfg->decode_method != 2 && cfg->decode_method != 5) return LNSFAID_E_INVAL;
+    if (cfg->max_iteration < 0 || cfg->max_iteration > (1 << 20)) return LNSFAID_E_INVAL;
+    if (cfg->max_bf_iter < 0 || cfg->max_bf_iter > (1 << 20)) return LNSFAID_E_INVAL;
+    if (cfg->regular_col_weight < 0 || cfg->regular_col_weight > LF_MAX_COLW) return LNSFAID_E_INVAL;
+    memset(out, 0, sizeof(*out));
+    out->method = cfg->decode_method;
+    out->max_iter = cfg->max_iteration;
+    out->factor_1 = (int8_t)cfg->factor_1; /* VECTOR_SET1: int8 lanes */
+    out->factor_2 = (int8_t)cfg->factor_2;
+    out->floor_err_count = cfg->floor_err_count;
+    out->floor_iter_thresh = cfg->floor_iter_thresh;
+    out->ef = cfg->ef_elimination;
+    out->max_bf = cfg->decode_method == 1 ? 0 : cfg->max_bf_iter; /* Decode_OMS has no BF stage */
+    out->L0 = cfg->bf_L0; out->L1 = cfg->bf_L1; out->alpha = cfg->bf_alpha; out->delta = cfg->bf_delta;
+    out->W = cfg->regular_col_weight;
+    out->hard2_thr = cfg->hard2_threshold;
+    if (cfg->decode_method == 5 && cfg->ef_elimination != 1) return LNSFAID_E_INVAL;
+    if (cfg->decode_method == 2 && cfg->ef_elimination != 0) return LNSFAID_E_INVAL;
+    for (int it = 0; it < 6; ++it)
+        for (int w = 0; w < 4; ++w) {
+            uint32_t l = 0, le = 0;
+            for (int a = 0; a < 8; ++a) {
+                const int v = cfg->v2c_map[it][w][a], ve = cfg->v2c_map_ef[it][w][a];
+                if (cfg->decode_method != 1 && (v < 0 || v > 7)) return LNSFAID_E_INVAL; /* 3-bit message alphabet */
+                if (cfg->decode_method == 5 && (ve < 0 || ve > 7)) return LNSFAID_E_INVAL;
+                l |= (uint32_t)(v & 15) << (4 * a);
+                le |= (uint32_t)(ve & 15) << (4 * a);
+            }
+            out->lut[it][w] = l;
+            out->lut_ef[it][w] = le;
+        }
+    return LNSFAID_OK;
+}
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+extern "C" void lnsfaid_destroy(lnsfaid_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->d_code); (void)hipFree(ctx->d_cfg); (void)hipFree(ctx->d_en); (void)hipFree(ctx->d_rows);
+    (void)hipFree(ctx->d_bits); (void)hipFree(ctx->d_lane); (void)hipFree(ctx->d_status[0]); (void)hipFree(ctx->d_status[1]);
+    (void)hipFree(ctx->d_remaining); (void)hipFree(ctx->d_counters);
+    (void)hipFree(ctx->d_io_in); (void)hipFree(ctx->d_io_out); (void)hipFree(ctx->d_io_stats);
+    if (ctx->h_remaining) (void)hipHostFree(ctx->h_remaining);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+static int create_impl(lnsfaid_ctx* ctx, const lnsfaid_code* code, const lnsfaid_cfg* cfg)
+{
+    int rc = build_code(code, &ctx->hcode);
+    if (rc) return rc;
+    rc = build_cfg(cfg, &ctx->hcfg);
+    if (rc) return rc;
+    ctx->n_var = ctx->hcode.n_var; ctx->n_check = ctx->hcode.n_check; ctx->k_info = ctx->hcode.k_info;
+    const size_t lds_main = ((size_t)ctx->n_var + 15) & ~(size_t)15;
+    const size_t lds_bf = (((size_t)3 * ctx->hcode.n_words + ctx->hcode.p_words + 2) * 4 + 15) & ~(size_t)15;
+    ctx->lds_bytes = (lds_main > lds_bf ? lds_main : lds_bf) + (LNSFAID_GROUP + 8) * sizeof(int);
+    if (ctx->lds_bytes > 64 * 1024) return LNSFAID_E_CODE;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || ctx->device < 0 || ctx->device >= ndev) {
+        snprintf(g_hip_err, sizeof(g_hip_err), "no usable HIP device (count %d, asked for %d)", ndev, ctx->device);
+        return LNSFAID_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&ctx->ev0));
+    HIP_TRY(hipEventCreate(&ctx->ev1));
+    const size_t n_cw = ctx->max_groups * LNSFAID_GROUP;
+    HIP_TRY(hipMalloc(&ctx->d_code, sizeof(LfDevCode)));
+    HIP_TRY(hipMalloc(&ctx->d_cfg, sizeof(LfDevCfg)));
+    HIP_TRY(hipMalloc(&ctx->d_en, n_cw * (size_t)ctx->n_var));
+    HIP_TRY(hipMalloc(&ctx->d_rows, n_cw * (size_t)ctx->hcode.nbr * LF_Z * sizeof(uint2)));
+    HIP_TRY(hipMalloc(&ctx->d_bits, n_cw * (size_t)3 * ctx->hcode.n_words * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_lane, n_cw * sizeof(LfLaneState)));
+    HIP_TRY(hipMalloc(&ctx->d_status[0], n_cw * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_status[1], n_cw * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_remaining, sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_counters, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc((void**)&ctx->h_remaining, sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&ctx->h_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipMemcpy(ctx->d_code, &ctx->hcode, sizeof(LfDevCode), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_cfg, &ctx->hcfg, sizeof(LfDevCfg), hipMemcpyHostToDevice));
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_create(lnsfaid_ctx** out, const lnsfaid_code* code, const lnsfaid_cfg* cfg, int32_t device,
+                              size_t max_groups)
+{
+    if (!out || !code || !cfg || max_groups == 0 || max_groups > ((size_t)1 << 24)) return LNSFAID_E_INVAL;
+    *out = nullptr;
+    lnsfaid_ctx* ctx = new (std::nothrow) lnsfaid_ctx();
+    if (!ctx) return LNSFAID_E_NOMEM;
+    ctx->device = device;
+    ctx->max_groups = max_groups;
+    const int rc = create_impl(ctx, code, cfg);
+    if (rc) { lnsfaid_destroy(ctx); return rc; }
+    *out = ctx;
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_set_cfg(lnsfaid_ctx* ctx, const lnsfaid_cfg* cfg)
+{
+    if (!ctx || !cfg) return LNSFAID_E_INVAL;
+    LfDevCfg n;
+    const int rc = build_cfg(cfg, &n);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->hcfg = n;
+    HIP_TRY(hipMemcpy(ctx->d_cfg, &ctx->hcfg, sizeof(LfDevCfg), hipMemcpyHostToDevice));
+    return LNSFAID_OK;
+}
+
+/* ---- the hot path ------------------------------------------------------------------------------------ */
+extern "C" int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput, size_t n_groups, int8_t* d_decodedBits,
+                                     lnsfaid_group_stats* d_stats)
+{
+    if (!ctx || (n_groups && (!d_fixInput || !d_decodedBits))) return LNSFAID_E_INVAL;
+    if (n_groups > ctx->max_groups) return LNSFAID_E_INVAL;
+    if (n_groups == 0) return LNSFAID_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n_cw = n_groups * LNSFAID_GROUP;
+    HIP_TRY(hipMemsetAsync(ctx->d_status[0], 0, n_cw * sizeof(int32_t), ctx->stream)); /* every codeword fresh */
+
+    LfKernelArgs a;
+    a.code = ctx->d_code; a.cfg = ctx->d_cfg;
+    a.fix_input = d_fixInput; a.decoded = d_decodedBits;
+    a.st_en = ctx->d_en; a.st_rows = ctx->d_rows; a.st_bits = ctx->d_bits; a.st_lane = ctx->d_lane;
+    a.remaining = ctx->d_remaining; a.stats = d_stats; a.n_cw = (int32_t)n_cw;
+
+    /* every launch moves each unfinished group's front forward or finishes it; the time line has
+     * max_iter + max_bf + 1 points and a group needs at most two launches per point */
+    const long max_launches = 2L * ((long)ctx->hcfg.max_iter + ctx->hcfg.max_bf + 2) + 2;
+    int cur = 0;
+    for (long launch = 0;; ++launch) {
+        if (launch >= max_launches) return LNSFAID_E_INTERNAL;
+        a.status_cur = ctx->d_status[cur];
+        a.status_next = ctx->d_status[cur ^ 1];
+        HIP_TRY(hipMemsetAsync(ctx->d_remaining, 0, sizeof(uint32_t), ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+        HIP_TRY(lf_launch_decode(ctx->hcfg.method, &a, ctx->lds_bytes, ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_remaining, ctx->d_remaining, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->kernel_ms += ms;
+        ctx->kernel_launches += 1;
+        cur ^= 1;
+        if (*ctx->h_remaining == 0) break;
+    }
+    return LNSFAID_OK;
+}
+
+static int ensure_io(lnsfaid_ctx* ctx)
+{
+    if (ctx->d_io_in) return LNSFAID_OK;
+    const size_t bytes = ctx->max_groups * LNSFAID_GROUP * (size_t)ctx->n_var;
+    HIP_TRY(hipMalloc(&ctx->d_io_in, bytes));
+    HIP_TRY(hipMalloc(&ctx->d_io_out, bytes));
+    HIP_TRY(hipMalloc(&ctx->d_io_stats, ctx->max_groups * sizeof(lnsfaid_group_stats)));
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, size_t n_groups, int8_t* decodedBits,
+                              lnsfaid_group_stats* stats)
+{
+    if (!ctx || (n_groups && (!fixInput || !decodedBits))) return LNSFAID_E_INVAL;
+    if (n_groups > ctx->max_groups) return LNSFAID_E_INVAL;
+    if (n_groups == 0) return LNSFAID_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_io(ctx);
+    if (rc) return rc;
+    const size_t bytes = n_groups * LNSFAID_GROUP * (size_t)ctx->n_var;
+    HIP_TRY(hipMemcpyAsync(ctx->d_io_in, fixInput, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = lnsfaid_decode_device(ctx, ctx->d_io_in, n_groups, ctx->d_io_out, ctx->d_io_stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(decodedBits, ctx->d_io_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (stats)
+        HIP_TRY(hipMemcpyAsync(stats, ctx->d_io_stats, n_groups * sizeof(lnsfaid_group_stats), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_count_errors_device(lnsfaid_ctx* ctx, const int8_t* d_decodedBits, const int8_t* d_inputBits,
+                                           size_t n_groups, uint64_t out[4])
+{
+    if (!ctx || !out || (n_groups && !d_decodedBits)) return LNSFAID_E_INVAL;
+    if (n_groups == 0) return LNSFAID_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(lf_launch_count_errors(d_decodedBits, d_inputBits, ctx->n_var, ctx->k_info, n_groups * LNSFAID_GROUP,
+                                   ctx->d_counters, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; ++i) out[i] += ctx->h_counters[i];
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_count_errors(lnsfaid_ctx* ctx, const int8_t* decodedBits, const int8_t* inputBits, size_t n_groups,
+                                    uint64_t out[4])
+{
+    if (!ctx || !out || (n_groups && !decodedBits)) return LNSFAID_E_INVAL;
+    if (n_groups > ctx->max_groups) return LNSFAID_E_INVAL;
+    if (n_groups == 0) return LNSFAID_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_io(ctx);
+    if (rc) return rc;
+    const size_t n_cw = n_groups * LNSFAID_GROUP;
+    HIP_TRY(hipMemcpyAsync(ctx->d_io_out, decodedBits, n_cw * (size_t)ctx->n_var, hipMemcpyHostToDevice, ctx->stream));
+    const int8_t* d_in = nullptr;
+    if (inputBits) {
+        /* [32][K] per group packed back to back fits in the (larger) fixInput staging buffer */
+        HIP_TRY(hipMemcpyAsync(ctx->d_io_in, inputBits, n_cw * (size_t)ctx->k_info, hipMemcpyHostToDevice, ctx->stream));
+        d_in = ctx->d_io_in;
+    }
+    return lnsfaid_count_errors_device(ctx, ctx->d_io_out, d_in, n_groups, out);
+}
+
+/* ---- measurement hooks / misc ---------------------------------------------------------------------- */
+extern "C" int lnsfaid_kernel_time(lnsfaid_ctx* ctx, double* out_ms, uint64_t* out_launches, int32_t reset)
+{
+    if (!ctx) return LNSFAID_E_INVAL;
+    if (out_ms) *out_ms = ctx->kernel_ms;
+    if (out_launches) *out_launches = ctx->kernel_launches;
+    if (reset) { ctx->kernel_ms = 0.0; ctx->kernel_launches = 0; }
+    return LNSFAID_OK;
+}
+
+extern "C" void* lnsfaid_stream(lnsfaid_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" const char* lnsfaid_strerror(int err)
+{
+    switch (err) {
+    case LNSFAID_OK: return "ok";
+    case LNSFAID_E_INVAL: return "invalid argument or unsupported configuration";
+    case LNSFAID_E_CODE: return "code table is not a supported quasi-cyclic code (Z = 256, degree 2..24, distinct block columns per block row)";
+    case LNSFAID_E_NOMEM: return "out of memory";
+    case LNSFAID_E_HIP: return "HIP runtime error";
+    case LNSFAID_E_NODEVICE: return "no usable GPU";
+    case LNSFAID_E_INTERNAL: return "internal error: relaunch loop did not converge";
+    default: return "unknown error";
+    }
+}
+
+extern "C" const char* lnsfaid_last_hip_error(void) { return g_hip_err; }
+extern "C" const char* lnsfaid_version(void) { return "lnsfaid-amd 0.1 (gfx950)"; }

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def abi():
+    import oracle_abi
+    return oracle_abi.pyabi
+
+
+@pytest.fixture(scope="session")
+def lib(abi):
+    return abi.load()
+
+
+@pytest.fixture(scope="session")
+def code50(abi, lib):
+    return abi.Code50GPON(lib)
