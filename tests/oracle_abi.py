@@ -112,3 +112,28 @@ class ReferenceChannel:
         for g in range(n_groups):
             self.lib.lnsfaid_frontend_qpsk_group(C.byref(self.fe), N, M, cw, sigma, self.scale, out[g].ctypes.data)
         return out.reshape(-1)
+
+
+def decode_mt(code50, cfg, fix_input, n_groups, threads=None):
+    """Oracle over n_groups groups with a pool of host threads (one oracle instance per thread)."""
+    import concurrent.futures
+    threads = max(1, min(threads or (os.cpu_count() or 1), n_groups, 16))
+    per = 32 * code50.N
+    oracles = [Oracle(code50, cfg) for _ in range(threads)]
+    outs = [None] * n_groups
+
+    def work(t):
+        for g in range(t, n_groups, threads):
+            outs[g] = oracles[t].decode(fix_input[g * per:(g + 1) * per], 1)
+
+    with concurrent.futures.ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(threads)))
+    return np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs])
+
+
+def synth_llr(n_groups, n_var, eb_n0, seed, scale=13.0, rate=ReferenceChannel.RATE):
+    """iid QPSK/AWGN LLRs of the all-zero codeword, quantised like float2LimitChar_4bit (numpy generator)."""
+    sigma = 1.0 / np.sqrt(rate * 2 * 10.0 ** (0.1 * eb_n0))
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(n_groups * 32 * n_var, dtype=np.float32) * np.float32(sigma / np.sqrt(2.0)) - np.float32(0.707107)
+    return np.clip(np.trunc(x * np.float32(scale)), -7, 7).astype(np.int8)
