@@ -1,0 +1,115 @@
+#include "CLDPC.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+static void die(const char* what, int rc)
+{
+    /* the reference's fatal path is exit(EXIT_FAILURE) (CTool.cpp:591-596); errors never pass silently */
+    fprintf(stderr, "%s failed: %d (%s; %s)\n", what, rc, lnsfaid_strerror(rc), lnsfaid_last_hip_error());
+    exit(EXIT_FAILURE);
+}
+
+CLDPC::CLDPC()
+    : m_Rate(0), inputBits(nullptr), outputBits(nullptr), decodedBits(nullptr), fixInput(nullptr), nb_iteration(0),
+      m_M(0), m_N(0), m_K(0), m_PunLen(0), m_ShortenLen(0), m_frame(0), m_groups(0), m_stats(nullptr), m_device(0),
+      m_factor_1(1), m_factor_2(6)
+{
+    memset(m_ctx, 0, sizeof(m_ctx));
+}
+
+CLDPC::~CLDPC()
+{
+    for (auto& c : m_ctx) lnsfaid_destroy(c);
+    free(inputBits); free(outputBits); free(decodedBits); free(fixInput); free(m_stats);
+}
+
+void CLDPC::Initial(int nb_frame, int MaxItertion, int groups, int device)
+{
+    if (nb_frame != LNSFAID_GROUP) { fprintf(stderr, "noFrames must be 32 (one group = 32 codewords)\n"); exit(EXIT_FAILURE); }
+    m_M = _NoCheck; m_K = NmoinsK; m_N = _NoVar; m_PunLen = _PunctureBits; m_ShortenLen = _ShortenBits;
+    m_Rate = 0.8444444; /* reference CLDPC.cpp:4780 */
+    m_frame = nb_frame; nb_iteration = MaxItertion; m_groups = groups; m_device = device;
+    const size_t frames = (size_t)groups * nb_frame;
+    inputBits = (int8_t*)calloc(frames * m_K, 1);
+    outputBits = (int8_t*)calloc(frames * m_N, 1);
+    decodedBits = (int8_t*)calloc(frames * m_N, 1);
+    fixInput = (int8_t*)calloc(frames * m_N, 1);
+    m_stats = (lnsfaid_group_stats*)calloc(groups, sizeof(lnsfaid_group_stats));
+    if (!inputBits || !outputBits || !decodedBits || !fixInput || !m_stats) die("allocation", LNSFAID_E_NOMEM);
+    /* the code definition comes from the Constants_SSE.h-format header, exactly as in the reference */
+    static const int32_t deg[] = { DEG_1, DEG_2, DEG_3 };
+    static const int32_t rows[] = { DEG_1_COMPUTATIONS, DEG_2_COMPUTATIONS, DEG_3_COMPUTATIONS };
+    for (int k = 0; k < NB_DEGRES; ++k) { m_deg[k] = deg[k]; m_deg_rows[k] = rows[k]; }
+    m_code.n_var = _NoVar; m_code.n_check = _NoCheck; m_code.n_edges = _NoOnes; m_code.z = 256;
+    m_code.puncture_tail = 384; /* reference CDecoder_FAID.cpp:253-255 */
+    m_code.nb_degres = NB_DEGRES; m_code.deg = m_deg; m_code.deg_rows = m_deg_rows; m_code.pos_vn = PosNoeudsVariable;
+}
+
+void CLDPC::FakeEncoder(const int* CodeWord_sym)
+{
+    /* reference CLDPC.cpp:163-207: every frame carries the same fixed codeword */
+    for (int g = 0; g < m_groups; ++g) {
+        int8_t* in = inputBits + (size_t)g * 32 * m_K;
+        int8_t* out = outputBits + (size_t)g * 32 * m_N;
+        for (int l = 0; l < 32; ++l) {
+            for (int j = 0; j < m_K; ++j) in[(size_t)l * m_K + j] = out[(size_t)l * m_K + j] = (int8_t)(CodeWord_sym ? CodeWord_sym[j] : 0);
+            for (int j = 0; j < m_M; ++j) out[(size_t)32 * m_K + (size_t)l * m_M + j] = (int8_t)(CodeWord_sym ? CodeWord_sym[m_K + j] : 0);
+        }
+    }
+}
+
+void CLDPC::float2LimitChar_4bit(int8_t* output, const float* input, float scale, size_t length)
+{
+    /* reference CLDPC.cpp:4553-4573: float multiply, truncate toward zero, saturating packs, clamp to +-7 */
+    for (size_t i = 0; i < length; ++i) {
+        const float y = input[i] * scale;
+        int q = (y > -2147483648.0f && y < 2147483648.0f) ? (int)y : (int)0x80000000;
+        q = q > 127 ? 127 : (q < -128 ? -128 : q);
+        output[i] = (int8_t)(q > 7 ? 7 : (q < -7 ? -7 : q));
+    }
+}
+
+void CLDPC::decode_with(int method)
+{
+    lnsfaid_cfg cfg;
+    int rc = lnsfaid_cfg_default(&cfg, method, nb_iteration);
+    if (rc) die("lnsfaid_cfg_default", rc);
+    cfg.factor_1 = m_factor_1;
+    cfg.factor_2 = m_factor_2;
+    if (!m_ctx[method]) {
+        rc = lnsfaid_create(&m_ctx[method], &m_code, &cfg, m_device, (size_t)m_groups);
+        if (rc) die("lnsfaid_create", rc);
+    } else {
+        rc = lnsfaid_set_cfg(m_ctx[method], &cfg);
+        if (rc) die("lnsfaid_set_cfg", rc);
+    }
+    rc = lnsfaid_decode(m_ctx[method], fixInput, (size_t)m_groups, decodedBits, m_stats);
+    if (rc) die("lnsfaid_decode", rc);
+}
+
+void CLDPC::Decode_OMS() { decode_with(1); }
+void CLDPC::Decode_FAID() { decode_with(2); }
+void CLDPC::Decode_FAID_2B1C() { decode_with(5); }
+
+Statistic CLDPC::CalculateErrors()
+{
+    lnsfaid_ctx* ctx = nullptr;
+    for (auto c : m_ctx) if (c) ctx = c;
+    if (!ctx) die("CalculateErrors before any Decode_*", LNSFAID_E_INVAL);
+    uint64_t out[4] = { 0, 0, 0, 0 };
+    const int rc = lnsfaid_count_errors(ctx, decodedBits, inputBits, (size_t)m_groups, out);
+    if (rc) die("lnsfaid_count_errors", rc);
+    Statistic s;
+    s.ErrorFrame = out[1]; s.ErrorBits = out[2]; s.LT3ErrBitFrame = out[3];
+    return s;
+}
+
+double CLDPC::KernelMs(bool reset)
+{
+    double total = 0;
+    for (auto c : m_ctx)
+        if (c) { double ms = 0; uint64_t n = 0; lnsfaid_kernel_time(c, &ms, &n, reset); total += ms; }
+    return total;
+}

@@ -1,0 +1,65 @@
+/*
+ * CLDPC.h — host-side mirror of the reference's `class CLDPC` (reference CLDPC.h:110-171) for the decode
+ * path.  Same member names and meaning for what callers touch (fixInput, decodedBits, inputBits, outputBits,
+ * nb_iteration, m_N/m_K/m_M/m_frame/m_Rate) and the same entry points; the bodies of Decode_OMS /
+ * Decode_FAID / Decode_FAID_2B1C / CalculateErrors are calls into the C ABI (include/lnsfaid.h).
+ *
+ * One extension: a CLDPC object can carry `m_groups` consecutive groups of 32 frames (the reference always
+ * has one), so that one Decode_*() call feeds the GPU a whole batch.  Buffers are then the reference's
+ * layout repeated per group.
+ */
+#ifndef CLDPC_H
+#define CLDPC_H
+#include <cstddef>
+#include <cstdint>
+
+#include "./Constants/Constants_SSE.h" /* generated: same macros and PosNoeudsVariable as the reference's header */
+#include "CTool.h"
+#include "lnsfaid.h"
+
+struct Statistic { /* reference CLDPC.h:103-108 */
+    unsigned long ErrorFrame;
+    unsigned long ErrorBits;
+    unsigned long LT3ErrBitFrame;
+};
+
+class CLDPC {
+public:
+    double m_Rate;
+    int8_t* inputBits;   /* [groups][32][K] information bits                                */
+    int8_t* outputBits;  /* [groups]([32][K] then [32][M]) encoder output, reference layout  */
+    int8_t* decodedBits; /* [groups][32][N] hard decisions                                   */
+    int8_t* fixInput;    /* [groups]([32][K] then [32][M]) quantised LLRs in [-7, 7]         */
+    int nb_iteration;
+    int m_M, m_N, m_K, m_PunLen, m_ShortenLen, m_frame;
+    int m_groups;
+
+    CLDPC();
+    ~CLDPC();
+    CLDPC(const CLDPC&) = delete;
+    CLDPC& operator=(const CLDPC&) = delete;
+
+    /* reference CLDPC::Initial(nb_frame, MaxIteration) plus the batch size and the GPU to use */
+    void Initial(int nb_frame, int MaxItertion, int groups = 1, int device = 0);
+    void FakeEncoder(const int* CodeWord_sym = nullptr); /* nullptr = the shipped all-zero CodeWord_sym */
+    void float2LimitChar_4bit(int8_t* output, const float* input, float scale, size_t length);
+
+    void Decode_OMS();       /* DecodeMethod 1 */
+    void Decode_FAID();      /* DecodeMethod 2 */
+    void Decode_FAID_2B1C(); /* DecodeMethod 5 */
+    Statistic CalculateErrors();
+
+    /* Factor_1 / Factor_2 as the reference re-reads them from Profile.txt on every decode call */
+    void SetFactors(int factor_1, int factor_2) { m_factor_1 = factor_1; m_factor_2 = factor_2; }
+    const lnsfaid_group_stats* GroupStats() const { return m_stats; }
+    double KernelMs(bool reset);
+
+private:
+    void decode_with(int method);
+    lnsfaid_ctx* m_ctx[6]; /* one context per DecodeMethod, created on first use */
+    lnsfaid_code m_code;
+    int32_t m_deg[NB_DEGRES], m_deg_rows[NB_DEGRES];
+    lnsfaid_group_stats* m_stats;
+    int m_device, m_factor_1, m_factor_2;
+};
+#endif

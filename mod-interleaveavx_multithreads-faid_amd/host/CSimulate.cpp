@@ -1,0 +1,120 @@
+#include "CSimulate.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#define BitsOverChannelLocal (_NoVar - _PunctureBits - _ShortenBits)
+
+/* seed table of the reference's worker threads (data, reference CSimulate.cpp:11-17) */
+static const int seed_table[] = { 101, 103, 107, 109, 113, 127, 131, 137, 139, 149, 151, 157, 163, 167, 173, 179, 181, 191,
+    193, 197, 199, 211, 223, 229, 233, 239, 241, 251, 257, 263, 269, 271, 277, 281, 283, 293, 307, 311, 313, 317, 331, 337,
+    347, 349, 353, 359, 367, 373, 379, 383, 389, 397, 401, 409, 419, 421, 431, 433, 439, 443, 449, 457, 461, 463, 467, 479,
+    487, 491, 499, 503, 507, 521, 523, 541, 547, 563, 569, 571, 577, 587, 593, 599, 601, 607, 613, 617, 619, 631, 641, 643,
+    647, 653, 659, 661, 673, 677, 683, 691, 701, 709, 719, 727, 733, 739, 743, 751, 757, 761, 769, 773, 787, 797, 809, 811,
+    821, 823, 827, 829, 839, 953, 857, 859, 863, 877, 881, 883, 887, 907, 911, 919, 929, 937, 941, 947, 953, 967, 971, 977,
+    983, 991, 997, 1009, 1013, 1019 };
+
+int SimulationSeed(int index)
+{
+    const int n = (int)(sizeof(seed_table) / sizeof(seed_table[0]));
+    /* beyond the reference's table (it would read out of bounds): keep going with distinct odd seeds */
+    return index < n ? seed_table[index] : 1021 + 2 * (index - n);
+}
+
+CSimulate::~CSimulate() { delete ldpc; }
+
+void CSimulate::Initial(Parameter_Simulation& p, int first_index, int streams, int device)
+{
+    scale = p.scale;
+    m_first = first_index;
+    m_streams = streams;
+    ModulationType = p.mod_type;
+    InterleaveModType = p.interleavemod_type;
+    if ((ModulationType != 1 && ModulationType != 2) || InterleaveModType != 1) {
+        fprintf(stderr, "host front-end supports modType 1 (BPSK) / 2 (QPSK) with InterleaveModType 1 only\n");
+        exit(EXIT_FAILURE);
+    }
+    ldpc = new CLDPC();
+    ldpc->Initial(p.nb_frames, p.Max_Iteration, streams, device);
+    ldpc->SetFactors(p.Factor_1, p.Factor_2);
+    const unsigned long SourceLen = (unsigned long)ldpc->m_frame * BitsOverChannelLocal;
+    const unsigned long SymbolLen = ModulationType == 1 ? SourceLen : SourceLen / 2; /* reference CModulate.cpp:66-74 */
+    channel.resize(streams);
+    for (int s = 0; s < streams; ++s) {
+        channel[s].RandomSeed = SimulationSeed(first_index + s);
+        channel[s].Initial(SymbolLen, first_index + s);
+    }
+}
+
+void CSimulate::Configure(float Eb_N0, int _decode_method)
+{
+    snr = Eb_N0; /* reference CSimulate.cpp:67-74 */
+    if (ModulationType == 1) sigma = (float)(1.0 / sqrt(2.0 * ldpc->m_Rate * ModulationType * pow(10.0, 0.1 * snr)));
+    else sigma = (float)(1.0 / sqrt(ldpc->m_Rate * ModulationType * pow(10.0, 0.1 * snr)));
+    decode_method = _decode_method;
+    TestFrame = ErrorFrame = ErrorBits = LT3ErrBitFrame = 0;
+}
+
+void CSimulate::Run()
+{
+    static const float table_qpsk[2] = { -0.707107f, 0.707107f }; /* reference CModulate.cpp:4 */
+    const int N = ldpc->m_N, K = ldpc->m_K, M = ldpc->m_M;
+    ldpc->FakeEncoder(); /* FAKE_ENCODE path (reference CSimulate.cpp:103-104): GenMatrix is not shipped */
+    /* interleave (identity for InterleaveModType 1) + modulate once, reference CSimulate.cpp:111-116.
+     * outputBits of a group is [32][K] then [32][M]; frame m's bit k sits at m*N + k after
+     * BeforeModulationInterleaver (CModulate.cpp:95-148). */
+    const int8_t* ob = ldpc->outputBits;
+    auto tx_bit = [&](int m, int k) { return k < K ? ob[(size_t)m * K + k] : ob[(size_t)32 * K + (size_t)m * M + (k - K)]; };
+    const size_t bits = (size_t)32 * N;
+    if (ModulationType == 1) {
+        BPSKModSeq.resize(bits);
+        for (int m = 0; m < 32; ++m) for (int k = 0; k < N; ++k) BPSKModSeq[(size_t)m * N + k] = 2.0f * tx_bit(m, k) - 1.0f; /* CModulate.cpp:368 */
+    } else {
+        ModSeq.resize(bits / 2);
+        for (size_t i = 0; i < bits / 2; ++i) {
+            const size_t b0 = 2 * i, b1 = 2 * i + 1;
+            ModSeq[i].real = table_qpsk[tx_bit((int)(b0 / N), (int)(b0 % N))];
+            ModSeq[i].imag = table_qpsk[tx_bit((int)(b1 / N), (int)(b1 % N))];
+        }
+    }
+    std::vector<float> llr((size_t)m_streams * bits);
+    for (int call = 0; call < 50; ++call) {
+        TestFrame += 32ul * m_streams;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int s = 0; s < m_streams; ++s) {
+            float* dst = llr.data() + (size_t)s * bits;
+            CChannel& ch = channel[s];
+            int8_t* fix = ldpc->fixInput + (size_t)s * bits;
+            if (ModulationType == 1) {
+                ch.BPSKAWGNChannel(BPSKModSeq.data(), sigma);
+                for (size_t i = 0; i < bits; ++i) dst[i] = ch.BPSKSymbol[i];
+            } else {
+                ch.AWGNChannel(ModSeq.data(), (float)(sigma / sqrt(2))); /* reference CSimulate.cpp:126 */
+                for (size_t i = 0; i < bits / 2; ++i) { dst[2 * i] = ch.SymbolSeq[i].real; dst[2 * i + 1] = ch.SymbolSeq[i].imag; } /* Demodulation, CModulate.cpp:276-281 */
+            }
+            /* AfterDeModulationDeInterleaver (CModulate.cpp:152-212) + float2LimitChar_4bit, frame-major -> [32][K] | [32][M] */
+            for (int m = 0; m < 32; ++m) {
+                ldpc->float2LimitChar_4bit(fix + (size_t)m * K, dst + (size_t)m * N, scale, (size_t)K);
+                ldpc->float2LimitChar_4bit(fix + (size_t)32 * K + (size_t)m * M, dst + (size_t)m * N + K, scale, (size_t)M);
+            }
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        switch (decode_method) { /* reference CSimulate.cpp:136-164 */
+        case 1: ldpc->Decode_OMS(); break;
+        case 2: ldpc->Decode_FAID(); break;
+        case 5: ldpc->Decode_FAID_2B1C(); break;
+        default:
+            fprintf(stderr, "DecodeMethod %d is not implemented on this path (1, 2, 5 are)\n", decode_method);
+            exit(EXIT_FAILURE);
+        }
+        decode_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (int s = 0; s < m_streams; ++s) { sum_iterations += ldpc->GroupStats()[s].iterations; sum_bf_iterations += ldpc->GroupStats()[s].bf_iterations; }
+        decoded_groups += m_streams;
+        const Statistic Test = ldpc->CalculateErrors();
+        ErrorFrame += Test.ErrorFrame;
+        ErrorBits += Test.ErrorBits;
+        LT3ErrBitFrame += Test.LT3ErrBitFrame;
+    }
+}

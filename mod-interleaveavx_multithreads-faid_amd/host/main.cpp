@@ -1,0 +1,116 @@
+/*
+ * main.cpp — Eb/N0 sweep driver, mirroring reference main.cpp:17-231 on top of the GPU decode path.
+ *
+ * Reads ./Profile.txt (same file as the reference), sweeps StartSNR..EndSNR in SNRPass steps, stops a point
+ * when TestFrame >= 1000 and ErrorFrame >= 20 (reference main.cpp:164, :209) and appends the same
+ * Result.txt / Temp.txt rows (columns of main.cpp:113-116, :219-222).
+ *
+ * Parallelism: the reference starts one pinned pthread per hardware thread, each with seed[index]
+ * (main.cpp:31-34, :166-172).  Here `--streams T` such workers (default 64) are partitioned into contiguous
+ * ranges over `--gpus G` GPUs; one host thread per GPU drives its CSimulate, and the per-GPU counters are
+ * summed on the host after each round exactly as reference main.cpp:174-182 does.  With T equal to the
+ * reference's thread count the printed counters are identical to the reference's.
+ */
+#include <sys/time.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <thread>
+#include <vector>
+
+#include "CSimulate.h"
+
+using namespace std;
+
+int main(int argc, char** argv)
+{
+    int streams = 64, gpus = 1, max_rounds = 0;
+    const char* profile = "Profile.txt";
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--streams") && i + 1 < argc) streams = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--profile") && i + 1 < argc) profile = argv[++i];
+        else if (!strcmp(argv[i], "--max-rounds") && i + 1 < argc) max_rounds = atoi(argv[++i]); /* 0 = reference stop rule only */
+        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R]\n", argv[0]); return 2; }
+    }
+    if (streams < 1 || gpus < 1 || gpus > streams) { fprintf(stderr, "need 1 <= gpus <= streams\n"); return 2; }
+
+    Parameter_Simulation p_simulation;
+    if (!ReadProfile(&p_simulation, profile)) {
+        cerr << "Cannot open Profile\n"; /* reference CTool.cpp:591-596 */
+        exit(EXIT_FAILURE);
+    }
+
+    /* contiguous stream ranges per GPU; never split a group (a stream IS a sequence of whole groups) */
+    vector<CSimulate> simulate(gpus);
+    for (int g = 0; g < gpus; ++g) {
+        const int first = (int)((long)streams * g / gpus), last = (int)((long)streams * (g + 1) / gpus);
+        simulate[g].Initial(p_simulation, first, last - first, g);
+    }
+
+    ofstream fout("Result.txt", std::ios::app);
+    if (!fout.is_open()) { cerr << "Cannot open Result.txt\n"; exit(EXIT_FAILURE); }
+    fout << endl
+         << "********************************************************************************************************************************************" << endl;
+    fout << "DATE:" << __DATE__ << endl << "Time" << __TIME__ << endl;
+    fout << "codeFile:" << MATRIX_FILE << endl;
+    fout << "DecodeMethod:" << p_simulation.decode_method << endl;
+    fout << "MaxItertion:" << p_simulation.Max_Iteration << endl;
+    fout << "Modulation Type" << p_simulation.mod_type << endl;
+    fout << "InterLeave ModType" << p_simulation.interleavemod_type << endl;
+    fout << "scale=" << p_simulation.scale << endl;
+    fout << "factor_1=" << p_simulation.Factor_1 << endl << "factor_2=" << p_simulation.Factor_2 << endl;
+    fout << "Punctue Number: " << _PunctureBits << " Shorten Bits" << _ShortenBits << " RATE: " << simulate[0].ldpc->m_Rate << endl;
+    fout << "streams=" << streams << " gpus=" << gpus << endl;
+    fout << setw(5) << "Eb_N0" << '\t' << setw(20) << "TestFrame" << '\t' << setw(15) << "ErrorFrame" << '\t' << setw(20) << "ErrorBits"
+         << '\t' << setw(20) << "FER" << '\t' << setw(20) << "BER" << '\t' << setw(15) << "LT3ErrBitFrame" << '\t' << setw(15) << "Time(s)" << '\t' << endl;
+    fout.close();
+    cout << setw(5) << "Eb_N0" << setw(20) << "TestFrame" << setw(15) << "ErrorFrame" << setw(20) << "ErrorBits" << setw(20) << "FER"
+         << setw(20) << "BER" << setw(15) << "LT3ErrBitFrame" << setw(15) << "Time(s)" << setw(18) << "decode info Gb/s" << endl;
+
+    for (float snr = p_simulation.snr_start; snr < p_simulation.snr_end; snr += p_simulation.snr_pass) {
+        unsigned long TestFrame = 0, ErrorFrame = 0, ErrorBits = 0, LT3ErrBitFrame = 0;
+        double BER = 0, FER = 0, decode_s = 0;
+        for (auto& s : simulate) { s.Configure(snr, p_simulation.decode_method); s.decode_seconds = 0; }
+        timeval t_start, t_end;
+        gettimeofday(&t_start, NULL);
+        int rounds = 0;
+        while (TestFrame < 1000 || ErrorFrame < 20) {
+            vector<thread> workers; /* Start()/End() of the reference: create + join per round (CSimulate.cpp:255-278) */
+            for (int g = 0; g < gpus; ++g) workers.emplace_back([&simulate, g]() { simulate[g].Run(); });
+            for (auto& w : workers) w.join();
+            for (auto& s : simulate) { /* reference main.cpp:174-182: the reference adds the running totals again each round */
+                TestFrame += s.TestFrame; ErrorFrame += s.ErrorFrame; ErrorBits += s.ErrorBits; LT3ErrBitFrame += s.LT3ErrBitFrame;
+            }
+            BER = (double)(ErrorBits > 0 ? ErrorBits : 1) / ((double)TestFrame * (NmoinsK - _ShortenBits));
+            FER = (double)(ErrorFrame > 0 ? ErrorFrame : 1) / TestFrame;
+            ofstream tout("Temp.txt", std::ios::out);
+            tout << setw(5) << snr << '\t' << setw(20) << TestFrame << '\t' << setw(15) << ErrorFrame << '\t' << setw(20) << ErrorBits << '\t'
+                 << setw(20) << FER << '\t' << setw(20) << BER << '\t' << setw(15) << LT3ErrBitFrame << '\t' << endl;
+            tout << "const unsigned long lastSeed[" << streams << "][3] = {\n"; /* resume table, reference main.cpp:200-207 */
+            for (auto& s : simulate)
+                for (auto& ch : s.channel) tout << setw(4) << '{' << ch.RS.IX << "," << ch.RS.IY << ',' << ch.RS.IZ << "},\n";
+            tout << "}\n";
+            tout.close();
+            ++rounds;
+            if (TestFrame > 1000 && ErrorFrame > 20) break;
+            if (max_rounds && rounds >= max_rounds) break;
+        }
+        gettimeofday(&t_end, NULL);
+        const double total_time = (t_end.tv_sec - t_start.tv_sec) + (t_end.tv_usec - t_start.tv_usec) / 1000000.0;
+        unsigned long groups = 0;
+        for (auto& s : simulate) { decode_s = decode_s > s.decode_seconds ? decode_s : s.decode_seconds; groups += s.decoded_groups; s.decoded_groups = 0; }
+        const double gbps = decode_s > 0 ? (double)groups * 32 * NmoinsK / decode_s / 1e9 : 0;
+        cout << setw(5) << snr << setw(20) << TestFrame << setw(15) << ErrorFrame << setw(20) << ErrorBits << setw(20) << FER << setw(20) << BER
+             << setw(15) << LT3ErrBitFrame << setw(15) << total_time << setw(18) << gbps << endl;
+        fout.open("Result.txt", std::ios::app);
+        fout << setw(5) << snr << '\t' << setw(20) << TestFrame << '\t' << setw(15) << ErrorFrame << '\t' << setw(20) << ErrorBits << '\t' << setw(20)
+             << FER << '\t' << setw(20) << BER << '\t' << setw(15) << LT3ErrBitFrame << '\t' << setw(15) << total_time << '\t' << endl;
+        fout.close();
+    }
+    return 0;
+}

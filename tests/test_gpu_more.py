@@ -1,0 +1,201 @@
+"""GPU parity, part 2: committed golden vectors, reference-anchored digests, the device-pointer entry points,
+BASELINE-size batches through size-independent properties, edge cases, and the C++ host driver."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_abi as oa
+from test_oracle import ANCHORS, GOLD, GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_golden_vectors(abi, code50, name):
+    z, fix, dec = load_golden(name, code50.N)
+    d = abi.Decoder(code50, abi.default_cfg(int(z["method"]), int(z["max_iter"])), 0, 1)
+    out, st = d.decode(fix, 1)
+    inp = None
+    if int(z["known_codeword"]):
+        cw = np.unpackbits(np.fromfile(os.path.join(GOLD, "codeword_50gpon.bin"), dtype=np.uint8))[:code50.N].astype(np.int8)
+        inp = np.ascontiguousarray(np.tile(cw[:code50.K], 32))
+    cnt = d.count_errors(out, inp, 1)
+    d.close()
+    assert np.array_equal(out, dec)
+    assert np.array_equal(st, z["stats"])
+    assert cnt == [int(x) for x in z["counters"]]
+
+
+@pytest.mark.parametrize("a", [ANCHORS[1], ANCHORS[2], ANCHORS[5], ANCHORS[6], ANCHORS[7]],
+                         ids=lambda a: "m%d_%.1fdB_it%d" % (a["method"], a["eb_n0"], a["max_iter"]))
+def test_reference_anchored_runs(abi, code50, a):
+    """30 calls of seed 101 at the survey's Eb/N0 points: the GPU must give the reference's recorded counters
+     and the oracle's digest of all hard decisions."""
+    fix = oa.ReferenceChannel(code50, a["seed"], 13.0).groups(a["eb_n0"], a["groups"])
+    d = abi.Decoder(code50, abi.default_cfg(a["method"], a["max_iter"]), 0, a["groups"])
+    out, st = d.decode(fix, a["groups"])
+    cnt = d.count_errors(out, None, a["groups"])
+    d.close()
+    assert cnt == [960, a["survey_frame_errors"], a["survey_bit_errors"], a["oracle_counters"][3]]
+    assert hashlib.sha256(out.tobytes()).hexdigest() == a["oracle_sha256"]
+    assert (int(st[:, 0].sum()), int(st[:, 1].sum())) == (a["oracle_sum_I"], a["oracle_sum_J"])
+
+
+@pytest.mark.parametrize("method,eb_n0", [(2, 3.6), (5, 3.55), (1, 3.7)])
+def test_large_batch_device_pointers(abi, code50, method, eb_n0):
+    """96 groups (3072 codewords, more than one wave of workgroups) through lnsfaid_decode_device /
+    lnsfaid_count_errors_device with torch-owned device memory, against the threaded oracle."""
+    import torch
+    ng, N = 96, code50.N
+    cfg = abi.default_cfg(method, 10)
+    fix = oa.synth_llr(ng, N, eb_n0, seed=7 + method)
+    ref, ref_st = oa.decode_mt(code50, cfg, fix, ng)
+    ref_cnt = oa.Oracle(code50, cfg).count_errors(ref, None, ng)
+    d_fix = torch.from_numpy(fix).cuda()
+    d_out = torch.empty(ng * 32 * N, dtype=torch.int8, device="cuda")
+    d_st = torch.zeros((ng, 2), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    d = abi.Decoder(code50, cfg, 0, 128)  # context larger than the batch
+    for _ in range(2):  # a context is reusable: same answer on the second call
+        d.decode_device(d_fix.data_ptr(), ng, d_out.data_ptr(), d_st.data_ptr())
+        cnt = d.count_errors_device(d_out.data_ptr(), None, ng)
+        assert np.array_equal(d_out.cpu().numpy(), ref)
+        assert np.array_equal(d_st.cpu().numpy(), ref_st)
+        assert cnt == ref_cnt
+    ms, launches = d.kernel_time()
+    assert ms > 0 and launches >= 2
+    d.close()
+
+
+def test_baseline_size_batch_properties(abi, code50):
+    """BASELINE.json configs[1] size (2048 groups = 65 536 codewords), checked by properties that need no
+    oracle run: noiseless codewords are fixed points (zero and the reference's known codeword, mixed per lane),
+    the error counters agree with a host recount, decoding is deterministic, and a sample of groups matches
+    the oracle."""
+    ng, N, K = 2048, code50.N, code50.K
+    cw = np.unpackbits(np.fromfile(os.path.join(GOLD, "codeword_50gpon.bin"), dtype=np.uint8))[:N].astype(np.int8)
+    cfg = abi.default_cfg(2, 10)
+    d = abi.Decoder(code50, cfg, 0, ng)
+    # (1) fixed points, with a few noisy groups mixed in so that groups stop at different points
+    frames = np.zeros((ng, 32, N), dtype=np.int8)
+    frames[:, 1::2] = cw
+    llr = np.where(frames > 0, 7, -7).astype(np.int8)
+    fix = np.concatenate([llr[:, :, :K].reshape(ng, -1), llr[:, :, K:].reshape(ng, -1)], axis=1)
+    noisy = oa.synth_llr(8, N, 3.5, seed=5).reshape(8, -1)
+    fix[::256] = noisy
+    fix = np.ascontiguousarray(fix.reshape(-1))
+    out, st = d.decode(fix, ng)
+    out3 = out.reshape(ng, 32, N)
+    clean = np.ones(ng, dtype=bool)
+    clean[::256] = False
+    assert np.array_equal(out3[clean], frames[clean])
+    assert (st[clean] == [1, 0]).all()
+    ref, ref_st = oa.decode_mt(code50, cfg, np.ascontiguousarray(noisy.reshape(-1)), 8)
+    assert np.array_equal(out3[::256].reshape(-1), ref) and np.array_equal(st[::256], ref_st)
+    # (2) counters == host recount of the same bits; (3) determinism
+    fix2 = oa.synth_llr(ng, N, 3.6, seed=11)
+    out2, st2 = d.decode(fix2, ng)
+    cnt = d.count_errors(out2, None, ng)
+    err = out2.reshape(ng * 32, N)[:, :K].astype(np.int64).sum(axis=1)
+    assert cnt == [ng * 32, int((err > 0).sum()), int(err.sum()), int(((err > 0) & (err < 3)).sum())]
+    out2b, st2b = d.decode(fix2, ng)
+    assert np.array_equal(out2, out2b) and np.array_equal(st2, st2b)
+    # (4) every decoded frame the decoder reports as converged satisfies all checks (syndrome of the output)
+    pos = np.ctypeslib.as_array(code50.pos_vn).astype(np.int64)
+    row_deg = np.repeat(np.array(list(code50.deg)), np.array(list(code50.deg_rows)))
+    starts = np.concatenate([[0], np.cumsum(row_deg)[:-1]])
+    early = np.nonzero(st2[:, 0] < 10)[0][:64]  # groups that stopped early: all 32 lanes were clean
+    assert early.size > 0
+    sample = out2.reshape(ng, 32, N)[early].reshape(-1, N)
+    synd = np.add.reduceat(sample[:, pos].astype(np.int64), starts, axis=1) & 1
+    assert not synd.any()
+    # sample parity with the oracle at this size
+    pick = [0, 777, 2047]
+    sub = np.concatenate([fix2.reshape(ng, -1)[g] for g in pick])
+    ref2, ref2_st = oa.decode_mt(code50, cfg, sub, len(pick))
+    assert np.array_equal(np.concatenate([out2.reshape(ng, -1)[g] for g in pick]), ref2)
+    assert np.array_equal(st2[pick], ref2_st)
+    d.close()
+
+
+def test_edge_cases(abi, lib, code50):
+    cfg = abi.default_cfg(2, 10)
+    d = abi.Decoder(code50, cfg, 0, 2)
+    assert lib.lnsfaid_decode(d.ctx, None, 0, None, None) == 0                      # empty batch
+    fix = oa.synth_llr(3, code50.N, 3.6, seed=1)
+    out = np.empty_like(fix)
+    assert lib.lnsfaid_decode(d.ctx, fix.ctypes.data, 3, out.ctypes.data, None) == -1   # more groups than the context holds
+    assert lib.lnsfaid_decode(d.ctx, None, 1, None, None) == -1
+    # all-erased input (every LLR 0): hard decisions are 0 everywhere, the group is clean at once
+    zeros = np.zeros(32 * code50.N, dtype=np.int8)
+    o, st = d.decode(zeros, 1)
+    assert not o.any() and st.tolist() == [[0, 0]]
+    # saturated, conflicting input (+7 everywhere = all-ones word, not a codeword): runs to the caps like the oracle
+    sevens = np.full(32 * code50.N, 7, dtype=np.int8)
+    o, st = d.decode(sevens, 1)
+    ro, rst = oa.Oracle(code50, cfg).decode(sevens, 1)
+    assert np.array_equal(o, ro) and np.array_equal(st, rst)
+    # set_cfg switches iteration cap and factors without a new context
+    cfg6 = abi.default_cfg(2, 6)
+    d.set_cfg(cfg6)
+    fx = oa.ReferenceChannel(code50, 107, 13.0).groups(3.6, 2)
+    o, st = d.decode(fx, 2)
+    ro, rst = oa.Oracle(code50, cfg6).decode(fx, 2)
+    assert np.array_equal(o, ro) and np.array_equal(st, rst)
+    d.close()
+
+
+def test_oms_factors_and_nondefault_tables(abi, code50):
+    """Profile.txt Factor_1/Factor_2 variants (OMS) and the reference's alternative LUT sets
+    (FAID32, reference CDecoder_FAID.cpp:51-88) go through the same kernels."""
+    fx = oa.ReferenceChannel(code50, 109, 13.0).groups(3.5, 2)
+    cfg = abi.default_cfg(1, 10)
+    cfg.factor_1, cfg.factor_2 = 2, 5
+    d = abi.Decoder(code50, cfg, 0, 2)
+    o, st = d.decode(fx, 2)
+    ro, rst = oa.Oracle(code50, cfg).decode(fx, 2)
+    assert np.array_equal(o, ro) and np.array_equal(st, rst)
+    d.close()
+    faid32 = [[0, 1, 1, 2, 3, 3, 3, 3], [0, 1, 1, 2, 3, 3, 3, 3], [0, 1, 1, 2, 4, 4, 4, 4],
+              [1, 1, 1, 1, 4, 4, 4, 4], [1, 1, 1, 1, 5, 5, 5, 5], [1, 1, 1, 1, 6, 6, 6, 6]]
+    cfg = abi.default_cfg(2, 10)
+    for it in range(6):
+        for w in range(4):
+            for a in range(8):
+                cfg.v2c_map[it][w][a] = faid32[it][a] + (1 if (w == 1 and a == 7 and it == 5) else 0)  # weight-6 row differs
+    d = abi.Decoder(code50, cfg, 0, 2)
+    o, st = d.decode(fx, 2)
+    ro, rst = oa.Oracle(code50, cfg).decode(fx, 2)
+    assert np.array_equal(o, ro) and np.array_equal(st, rst)
+    d.close()
+
+
+def test_host_driver_sweep_point_matches_oracle(abi, code50, tmp_path):
+    """The CLDPC/CSimulate-shaped C++ driver (host/lnsfaid_sim): 4 streams (reference threads 0..3, seeds
+    101, 103, 107, 109), one round of 50 calls at 3.5 dB, DecodeMethod 2; counters against the oracle fed by
+    the restated channel with the same seeds."""
+    exe = os.path.join(oa.PKG_DIR, "host", "lnsfaid_sim")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(oa.PKG_DIR, "host")])
+    prof = open(os.path.join(oa.PKG_DIR, "host", "Profile.txt")).read()
+    prof = prof.replace("StartSNR: 3.3", "StartSNR: 3.5").replace("EndSNR: 3.85", "EndSNR: 3.55")
+    (tmp_path / "Profile.txt").write_text(prof)
+    res = subprocess.run([exe, "--streams", "4", "--gpus", "1", "--max-rounds", "1"], cwd=tmp_path, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    row = [l for l in res.stdout.splitlines() if re.match(r"\s*3\.5\s", l)][-1].split()
+    got = [int(row[1]), int(row[2]), int(row[3]), int(row[6])]
+    cfg = abi.default_cfg(2, 10)
+    want = [0, 0, 0, 0]
+    for s, seed in enumerate([101, 103, 107, 109]):
+        fix = oa.ReferenceChannel(code50, seed, 13.0).groups(3.5, 50)
+        dec, _ = oa.decode_mt(code50, cfg, fix, 50)
+        c = oa.Oracle(code50, cfg).count_errors(dec, None, 50)
+        want = [w + x for w, x in zip(want, c)]
+    assert got == want, (got, want, res.stdout)
+    assert (tmp_path / "Result.txt").exists() and (tmp_path / "Temp.txt").exists()

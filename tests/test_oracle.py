@@ -1,0 +1,92 @@
+"""CPU tests of the oracle itself: pinned to the reference, to the committed golden vectors, and checked on
+size-independent properties.  (The oracle is test infrastructure; these tests are what make it trustworthy.)"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_abi as oa
+
+GOLD = os.path.join(oa.ROOT, "tests", "golden")
+ANCHORS = json.load(open(os.path.join(GOLD, "anchors.json")))
+GOLDEN = ["m2_3p5dB_g0", "m2_4p2dB_g0", "m1_3p5dB_g1", "m5_3p5dB_g2", "m2_3p55dB_cw_g0"]
+
+
+def unpack_llr(packed):
+    out = np.empty(packed.size * 2, dtype=np.int8)
+    out[0::2] = (packed & 15).astype(np.int8) - 8
+    out[1::2] = (packed >> 4).astype(np.int8) - 8
+    return out
+
+
+def load_golden(name, n_var):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    fix = unpack_llr(z["fix_packed"])
+    dec = np.unpackbits(z["decoded_packed"])[:32 * n_var].astype(np.int8)
+    return z, fix, dec
+
+
+@pytest.mark.parametrize("a", ANCHORS[2:3] + ANCHORS[5:7] + ANCHORS[7:8] + ANCHORS[0:1],
+                         ids=lambda a: "m%d_%.1fdB_it%d" % (a["method"], a["eb_n0"], a["max_iter"]))
+def test_oracle_reproduces_the_reference_counters_recorded_by_the_survey(abi, code50, a):
+    """the reference's own run in this container (seed 101, 30 calls) gave these
+    frame-error / bit-error counts; the oracle driven by the restated channel must give the same."""
+    cfg = abi.default_cfg(a["method"], a["max_iter"])
+    fix = oa.ReferenceChannel(code50, a["seed"], 13.0).groups(a["eb_n0"], a["groups"])
+    dec, st = oa.decode_mt(code50, cfg, fix, a["groups"])
+    cnt = oa.Oracle(code50, cfg).count_errors(dec, None, a["groups"])
+    assert cnt[0] == 960 and cnt[1] == a["survey_frame_errors"] and cnt[2] == a["survey_bit_errors"]
+    assert hashlib.sha256(dec.tobytes()).hexdigest() == a["oracle_sha256"]
+    assert (int(st[:, 0].sum()), int(st[:, 1].sum())) == (a["oracle_sum_I"], a["oracle_sum_J"])
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_oracle_against_golden_vectors(abi, code50, name):
+    z, fix, dec = load_golden(name, code50.N)
+    cfg = abi.default_cfg(int(z["method"]), int(z["max_iter"]))
+    out, st = oa.Oracle(code50, cfg).decode(fix, 1)
+    assert np.array_equal(out, dec)
+    assert np.array_equal(st, z["stats"])
+
+
+def test_golden_inputs_come_from_the_restated_channel(code50):
+    z, fix, _ = load_golden("m2_3p5dB_g0", code50.N)
+    regen = oa.ReferenceChannel(code50, int(z["seed"]), 13.0).groups(float(z["eb_n0"]), 1)
+    assert np.array_equal(regen, fix)
+    assert fix.min() >= -7 and fix.max() <= 7
+
+
+@pytest.mark.parametrize("method", [1, 2, 5])
+def test_noiseless_codewords_are_fixed_points(abi, code50, method):
+    """A valid codeword at full confidence decodes to itself (the 384 erased tail VNs are recovered by the first
+    iteration, the group then stops at the next syndrome check); lane order is kept."""
+    cw = np.unpackbits(np.fromfile(os.path.join(GOLD, "codeword_50gpon.bin"), dtype=np.uint8))[:code50.N].astype(np.int8)
+    N, K, M = code50.N, code50.K, code50.M
+    frames = np.zeros((32, N), dtype=np.int8)
+    frames[1::2] = cw  # odd lanes carry the known codeword, even lanes the all-zero word
+    llr = np.where(frames > 0, 7, -7).astype(np.int8)
+    fix = np.concatenate([llr[:, :K].reshape(-1), llr[:, K:].reshape(-1)])
+    out, st = oa.Oracle(code50, abi.default_cfg(method, 10)).decode(fix, 1)
+    out = out.reshape(32, N)
+    assert st.tolist() == [[1, 0]]
+    assert np.array_equal(out, frames)
+
+
+def test_empty_batch_and_bad_arguments(abi, code50):
+    o = oa.Oracle(code50, abi.default_cfg(2, 10))
+    assert o.lib.lnsfaid_oracle_decode(o.h, None, 0, None, None) == 0
+    assert o.lib.lnsfaid_oracle_decode(o.h, None, 1, None, None) == -1
+
+
+def test_count_errors_rule(abi, code50):
+    """CalculateErrors counts information bits only; 1-2 wrong bits also count as LT3ErrBitFrame."""
+    N, K = code50.N, code50.K
+    dec = np.zeros((2, 32, N), dtype=np.int8)
+    dec[0, 3, 5] = 1
+    dec[0, 4, [1, 2, 3]] = 1
+    dec[1, 0, K + 7] = 1  # parity-bit error: not counted
+    dec[1, 31, [0, K - 1]] = 1
+    cnt = oa.Oracle(code50, abi.default_cfg(2, 10)).count_errors(dec.reshape(-1), None, 2)
+    assert cnt == [64, 3, 6, 2]
