@@ -93,6 +93,10 @@ def main():
     import torch
     import oracle_abi as oa
     pyabi = oa.pyabi
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lnsfaid_dist", os.path.join(oa.PKG_DIR, "dist.py"))
+    lnsfaid_dist = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lnsfaid_dist)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -119,7 +123,6 @@ def main():
 
     d_out = torch.empty((n_groups, 32 * N_VAR), dtype=torch.int8, device=device)
     d_stats = torch.zeros((n_groups, 2), dtype=torch.int32, device=device)
-    counters_dev = torch.zeros(4, dtype=torch.int64, device=device)
 
     def barrier():
         torch.cuda.synchronize()
@@ -136,10 +139,8 @@ def main():
             nonlocal totals
             dec.decode_device(d_fix.data_ptr(), n_groups, d_out.data_ptr(), d_stats.data_ptr())
             c = dec.count_errors_device(d_out.data_ptr(), None, n_groups)
-            counters_dev.copy_(torch.tensor(c, dtype=torch.int64))
-            if dist is not None:
-                dist.all_reduce(counters_dev)  # RCCL: the path's only exchange (reference main.cpp:174-182)
-            totals = counters_dev.tolist()
+            # RCCL all-reduce of the 4 counters: the path's only exchange (reference main.cpp:174-182)
+            totals = lnsfaid_dist.allreduce_counters(c, dist, device)
 
         for _ in range(warmup):
             step()

@@ -8,6 +8,18 @@ if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
 
+def pytest_sessionstart(session):
+    """Initialise torch's HIP runtime BEFORE liblnsfaid.so is loaded.  torch ships its own libamdhip64; when
+    the system one (pulled in by liblnsfaid.so) is mapped first, torch afterwards reports "No HIP GPUs".
+    Tests use torch only as a device-memory allocator for the device-pointer entry points."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
