@@ -15,7 +15,8 @@
 
 #include "lnsfaid_device.h"
 
-extern "C" hipError_t lf_launch_decode(int method, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t lf_launch_decode(int method, int uniform_w, const LfKernelArgs* args, size_t lds_bytes,
+                                       hipStream_t stream);
 extern "C" hipError_t lf_launch_count_errors(const int8_t* decoded, const int8_t* input_bits, int n_var, int k_info,
                                              size_t n_cw, unsigned long long* out, hipStream_t stream);
 
@@ -44,7 +45,7 @@ struct lnsfaid_ctx {
     LfDevCode* d_code = nullptr;
     LfDevCfg* d_cfg = nullptr;
     int8_t* d_en = nullptr;
-    uint2* d_rows = nullptr;
+    uint4* d_rows = nullptr;
     uint32_t* d_bits = nullptr;
     LfLaneState* d_lane = nullptr;
     int32_t* d_status[2] = { nullptr, nullptr };
@@ -72,7 +73,7 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
     if (N <= 0 || M <= 0 || N % Z || M % Z || M >= N) return LNSFAID_E_CODE;
     const int nbr = M / Z, nbc = N / Z, K = N - M;
     if (nbr > LF_MAX_BR || nbc > LF_MAX_BC) return LNSFAID_E_CODE;
-    if (K % 4 || M % 4 || N % 64) return LNSFAID_E_CODE; /* dword staging, 64-wide ballots over VNs */
+    if (K % 4 || M % 4 || N % LF_T) return LNSFAID_E_CODE; /* dword staging, 64-wide ballots over VNs */
     if (code->puncture_tail < 0 || code->puncture_tail > N) return LNSFAID_E_CODE;
     /* degree of each check row from the DEG_k / DEG_k_COMPUTATIONS classes */
     std::vector<int> row_deg;
@@ -89,20 +90,22 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
         const int deg = row_deg[(size_t)br * Z];
         out->deg[br] = deg;
         const uint16_t* row0 = code->pos_vn + e;
+        for (int j = 0; j < 32; ++j) out->syn[br][j] = 0xffffffffu;
         int prev_cb = -1;
         for (int j = 0; j < deg; ++j) {
             const int cb = row0[j] / Z, sh = row0[j] % Z;
             if (row0[j] >= N || cb <= prev_cb) return LNSFAID_E_CODE; /* ascending, no block column twice */
             prev_cb = cb;
-            out->circ[br][j] = (uint32_t)cb | ((uint32_t)sh << 8);
+            out->circ[br][j].shift = (uint32_t)sh;
+            out->circ[br][j].base = (uint32_t)cb * (uint32_t)Z;
+            out->syn[br][j] = (uint32_t)sh | ((uint32_t)cb << 8);
             if (out->col_weight[cb] >= LF_MAX_COLW) return LNSFAID_E_CODE;
             out->colcirc[cb][out->col_weight[cb]++] = (uint32_t)br | ((uint32_t)sh << 8);
         }
         for (int i = 0; i < Z; ++i) {
             if (row_deg[(size_t)br * Z + i] != deg) return LNSFAID_E_CODE;
             for (int j = 0; j < deg; ++j) {
-                const uint32_t ci = out->circ[br][j];
-                const int want = (int)(ci & 0xff) * Z + (int)((((ci >> 8) & 0xff) + (uint32_t)i) % (uint32_t)Z);
+                const int want = (int)out->circ[br][j].base + (int)((out->circ[br][j].shift + (uint32_t)i) % (uint32_t)Z);
                 if (code->pos_vn[e + (size_t)i * deg + j] != want) return LNSFAID_E_CODE; /* not quasi-cyclic */
             }
         }
@@ -110,11 +113,19 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
     }
     for (int br = 0; br < nbr; ++br)
         for (int j = 0; j < out->deg[br]; ++j)
-            out->circ[br][j] |= (uint32_t)weight_class(out->col_weight[out->circ[br][j] & 0xff]) << 16;
+            out->circ[br][j].shift |= (uint32_t)weight_class(out->col_weight[out->circ[br][j].base / (uint32_t)Z]) << 16;
     out->n_var = N; out->n_check = M; out->k_info = K; out->nbr = nbr; out->nbc = nbc;
     out->puncture_tail = code->puncture_tail;
     out->n_words = N / 32; out->p_words = M / 32;
     return LNSFAID_OK;
+}
+
+/* block columns the bit-flipping stage may touch: column weight == REGULAR_COL_WEIGHT */
+static void build_wcols(LfDevCode* code, int W)
+{
+    code->n_wcols = 0;
+    for (int cb = 0; cb < code->nbc; ++cb)
+        if (code->col_weight[cb] == W) code->wcol[code->n_wcols++] = cb;
 }
 
 static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
@@ -138,19 +149,24 @@ static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
     out->hard2_thr = cfg->hard2_threshold;
     if (cfg->decode_method == 5 && cfg->ef_elimination != 1) return LNSFAID_E_INVAL;
     if (cfg->decode_method == 2 && cfg->ef_elimination != 0) return LNSFAID_E_INVAL;
+    out->uniform_w = 1;
     for (int it = 0; it < 6; ++it)
         for (int w = 0; w < 4; ++w) {
-            uint32_t l = 0, le = 0;
             for (int a = 0; a < 8; ++a) {
                 const int v = cfg->v2c_map[it][w][a], ve = cfg->v2c_map_ef[it][w][a];
                 if (cfg->decode_method != 1 && (v < 0 || v > 7)) return LNSFAID_E_INVAL; /* 3-bit message alphabet */
                 if (cfg->decode_method == 5 && (ve < 0 || ve > 7)) return LNSFAID_E_INVAL;
-                l |= (uint32_t)(v & 15) << (4 * a);
-                le |= (uint32_t)(ve & 15) << (4 * a);
+                uint32_t* l = a < 4 ? &out->lut_lo[it][w] : &out->lut_hi[it][w];
+                uint32_t* le = a < 4 ? &out->lut_ef_lo[it][w] : &out->lut_ef_hi[it][w];
+                *l |= (uint32_t)(v & 0xff) << (8 * (a & 3));
+                *le |= (uint32_t)(ve & 0xff) << (8 * (a & 3));
             }
-            out->lut[it][w] = l;
-            out->lut_ef[it][w] = le;
+            if (out->lut_lo[it][w] != out->lut_lo[it][0] || out->lut_hi[it][w] != out->lut_hi[it][0]) out->uniform_w = 0;
+            if (cfg->decode_method == 5
+                && (out->lut_ef_lo[it][w] != out->lut_ef_lo[it][0] || out->lut_ef_hi[it][w] != out->lut_ef_hi[it][0]))
+                out->uniform_w = 0;
         }
+    out->bf_fast = (out->W == 3 && ((int8_t)out->alpha == 0 || (int8_t)out->alpha == 1)) ? 1 : 0;
     return LNSFAID_OK;
 }
 
@@ -179,9 +195,8 @@ static int create_impl(lnsfaid_ctx* ctx, const lnsfaid_code* code, const lnsfaid
     rc = build_cfg(cfg, &ctx->hcfg);
     if (rc) return rc;
     ctx->n_var = ctx->hcode.n_var; ctx->n_check = ctx->hcode.n_check; ctx->k_info = ctx->hcode.k_info;
-    const size_t lds_main = ((size_t)ctx->n_var + 15) & ~(size_t)15;
-    const size_t lds_bf = (((size_t)3 * ctx->hcode.n_words + ctx->hcode.p_words + 2) * 4 + 15) & ~(size_t)15;
-    ctx->lds_bytes = (lds_main > lds_bf ? lds_main : lds_bf) + (LNSFAID_GROUP + 8) * sizeof(int);
+    build_wcols(&ctx->hcode, ctx->hcfg.W);
+    ctx->lds_bytes = lf_lds_bytes(ctx->n_var, ctx->hcode.n_words, ctx->hcode.p_words);
     if (ctx->lds_bytes > 64 * 1024) return LNSFAID_E_CODE;
 
     int ndev = 0;
@@ -197,7 +212,7 @@ static int create_impl(lnsfaid_ctx* ctx, const lnsfaid_code* code, const lnsfaid
     HIP_TRY(hipMalloc(&ctx->d_code, sizeof(LfDevCode)));
     HIP_TRY(hipMalloc(&ctx->d_cfg, sizeof(LfDevCfg)));
     HIP_TRY(hipMalloc(&ctx->d_en, n_cw * (size_t)ctx->n_var));
-    HIP_TRY(hipMalloc(&ctx->d_rows, n_cw * (size_t)ctx->hcode.nbr * LF_Z * sizeof(uint2)));
+    HIP_TRY(hipMalloc(&ctx->d_rows, n_cw * (size_t)ctx->hcode.nbr * LF_T * sizeof(uint4)));
     HIP_TRY(hipMalloc(&ctx->d_bits, n_cw * (size_t)3 * ctx->hcode.n_words * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&ctx->d_lane, n_cw * sizeof(LfLaneState)));
     HIP_TRY(hipMalloc(&ctx->d_status[0], n_cw * sizeof(int32_t)));
@@ -234,6 +249,10 @@ extern "C" int lnsfaid_set_cfg(lnsfaid_ctx* ctx, const lnsfaid_cfg* cfg)
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n.W != ctx->hcfg.W) { /* the bit-flipping column list depends on REGULAR_COL_WEIGHT */
+        build_wcols(&ctx->hcode, n.W);
+        HIP_TRY(hipMemcpy(ctx->d_code, &ctx->hcode, sizeof(LfDevCode), hipMemcpyHostToDevice));
+    }
     ctx->hcfg = n;
     HIP_TRY(hipMemcpy(ctx->d_cfg, &ctx->hcfg, sizeof(LfDevCfg), hipMemcpyHostToDevice));
     return LNSFAID_OK;
@@ -266,7 +285,7 @@ extern "C" int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput,
         a.status_next = ctx->d_status[cur ^ 1];
         HIP_TRY(hipMemsetAsync(ctx->d_remaining, 0, sizeof(uint32_t), ctx->stream));
         HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-        HIP_TRY(lf_launch_decode(ctx->hcfg.method, &a, ctx->lds_bytes, ctx->stream));
+        HIP_TRY(lf_launch_decode(ctx->hcfg.method, ctx->hcfg.uniform_w, &a, ctx->lds_bytes, ctx->stream));
         HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(hipMemcpyAsync(ctx->h_remaining, ctx->d_remaining, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -9,7 +9,8 @@
 
 #include "lnsfaid.h"
 
-#define LF_Z 256        /* circulant size = threads per workgroup: thread i owns check row i of every layer */
+#define LF_Z 256        /* circulant size                                                                  */
+#define LF_T 128        /* threads per workgroup: thread i owns check rows i and i + 128 of every layer     */
 #define LF_MAX_BR 32    /* block rows (layers); 50G-PON: 12   */
 #define LF_MAX_DEG 24   /* check degree;        50G-PON: 23   */
 #define LF_MAX_BC 256   /* block columns;       50G-PON: 69   */
@@ -18,20 +19,32 @@
 #define LF_DONE 0x40000000 /* status flag: codeword finished; low bits keep its last decision point */
 #define LF_PROG_MASK 0x0fffffff
 
-/* Quasi-cyclic view of the reference's PosNoeudsVariable table, read with scalar loads. */
+struct LfCirc {
+    uint32_t shift; /* circulant shift | weight class << 16             */
+    uint32_t base;  /* block column * 256 = LDS byte offset of the block */
+};
+
+/* Quasi-cyclic view of the reference's PosNoeudsVariable table.  Uniformly indexed fields are read with
+ * scalar loads (constant address space), lane-indexed ones (syn, colcirc, wcol) with vector loads. */
 struct LfDevCode {
     int32_t n_var, n_check, k_info, nbr, nbc, puncture_tail, n_words /* n_var / 32 */, p_words /* n_check / 32 */;
+    int32_t n_wcols;                          /* block columns whose weight equals REGULAR_COL_WEIGHT           */
     int32_t deg[LF_MAX_BR];
-    uint32_t circ[LF_MAX_BR][LF_MAX_DEG];     /* block column | shift << 8 | weight class << 16 */
+    LfCirc circ[LF_MAX_BR][LF_MAX_DEG];
+    uint32_t syn[LF_MAX_BR][32];              /* lane j: shift | block column << 8 of circulant j, ~0u beyond deg */
     int32_t col_weight[LF_MAX_BC];
-    uint32_t colcirc[LF_MAX_BC][LF_MAX_COLW]; /* block row | shift << 8 for every circulant of the column */
+    int32_t wcol[LF_MAX_BC];                  /* the n_wcols block columns of weight W                           */
+    uint32_t colcirc[LF_MAX_BC][LF_MAX_COLW]; /* block row | shift << 8 for every circulant of the column         */
 };
 
 struct LfDevCfg {
     int32_t method, max_iter, factor_1, factor_2, floor_err_count, floor_iter_thresh, ef, max_bf;
     int32_t L0, L1, alpha, delta, W, hard2_thr;
-    uint32_t lut[6][4];    /* V2C_map_it{1..6}_[class], 8 nibbles: entry a in bits 4a..4a+3 */
-    uint32_t lut_ef[6][4]; /* V2C_map_it{1..6}_ef                                            */
+    int32_t uniform_w; /* all four weight classes carry the same table rows (true for every shipped set)      */
+    int32_t bf_fast;   /* W == 3 and alpha in {0, 1}: bit-sliced flip decision                                */
+    /* V2C_map_it{1..6}_[class] as 8 bytes for v_perm_b32: lo = entries 0..3, hi = entries 4..7 */
+    uint32_t lut_lo[6][4], lut_hi[6][4];
+    uint32_t lut_ef_lo[6][4], lut_ef_hi[6][4];
 };
 
 /* Per-codeword scalars of the bit-flipping stage that survive a pause. */
@@ -44,8 +57,8 @@ struct LfKernelArgs {
     const LfDevCfg* cfg;
     const int8_t* fix_input;      /* reference fixInput layout, per group [32][K] then [32][M]           */
     int8_t* decoded;              /* reference decodedBits layout, per group [32][N]                      */
-    int8_t* st_en;                /* [n_cw][n_var]   a-posteriori LLRs En of paused codewords              */
-    uint2* st_rows;               /* [n_cw][nbr][256] compressed check-to-variable messages, see kernels   */
+    int8_t* st_en;                /* [n_cw][n_var]   a-posteriori LLRs En of parked codewords              */
+    uint4* st_rows;               /* [n_cw][nbr][128] compressed check-to-variable messages of a row pair  */
     uint32_t* st_bits;            /* [n_cw][3][n_words] hard / hard_ch / hard2 bit planes (BF stage)       */
     LfLaneState* st_lane;         /* [n_cw]                                                               */
     const int32_t* status_cur;    /* [n_cw] decision point each codeword is parked at (snapshot)          */
@@ -54,5 +67,18 @@ struct LfKernelArgs {
     lnsfaid_group_stats* stats;   /* [n_groups] or null                                                   */
     int32_t n_cw;
 };
+
+/* dynamic LDS carve-up, shared by host (size) and device (offsets) */
+static inline __host__ __device__ uint32_t lf_lds_off_hard(int n_var) { return ((uint32_t)n_var + 15u) & ~15u; }
+static inline __host__ __device__ uint32_t lf_lds_off_hard2(int n_var, int n_words) { return lf_lds_off_hard(n_var) + (uint32_t)n_words * 4u; }
+static inline __host__ __device__ uint32_t lf_lds_off_p(int n_var, int n_words) { return lf_lds_off_hard2(n_var, n_words) + (uint32_t)n_words * 4u; }
+static inline __host__ __device__ uint32_t lf_lds_off_stat(int n_var, int n_words, int p_words)
+{
+    return (lf_lds_off_p(n_var, n_words) + ((uint32_t)p_words + 2u) * 4u + 15u) & ~15u;
+}
+static inline __host__ __device__ uint32_t lf_lds_bytes(int n_var, int n_words, int p_words)
+{
+    return lf_lds_off_stat(n_var, n_words, p_words) + (LNSFAID_GROUP + 8) * 4u;
+}
 
 #endif

@@ -1,21 +1,25 @@
 /*
  * lnsfaid_kernels.hip — CDNA4 (gfx950) kernels of the batched LDPC decode hot path.
  *
- * Mapping.  The reference interleaves 32 codewords in the int8 lanes of one AVX
- * register and walks the 3072 check rows serially (CDecoder_FAID.cpp:631-1527).  Here one 256-thread
- * workgroup owns ONE codeword and thread i owns check row i of every layer (block row) of the
- * quasi-cyclic H: the 256 rows of a layer touch disjoint variable nodes (no block row repeats a block
- * column), so a layer is one parallel step and the reference's row-serial schedule is reproduced
- * exactly by running the 12 layers in order with a barrier in between.
- *   - a-posteriori LLRs En (int8, 17664 B) live in LDS for the whole launch; a circulant with shift s
- *     makes lane i touch byte (s + i) mod 256 of its block column: conflict-free, wrap included;
- *   - check-to-variable messages are never stored per edge (the reference keeps 70400 bytes per
- *     codeword, CLDPC.h:123).  A row's outgoing messages are +-c1 on the edge holding the first
- *     minimum and +-c2 elsewhere, so 8 bytes per row {sign bits | argmin, c1, c2} reproduce every Lmn
- *     bit for bit (proof of the tie case in DESIGN.md §3.2); they stream through global memory one
- *     layer ahead of use (coalesced 8 B per lane);
- *   - per-row reductions (min1 / min2 / argmin / sign parity) are register-serial over the <= 24
- *     edges of the row; the per-codeword syndrome weight is a wave ballot + popcount.
+ * Mapping.  The reference interleaves 32 codewords in the int8 lanes of one AVX register
+ * and walks the 3072 check rows serially (CDecoder_FAID.cpp:631-1527).  Here one 128-thread workgroup
+ * (two wavefronts) owns ONE codeword and thread i owns check rows i and i+128 of every layer (block row) of
+ * the quasi-cyclic H.  The 256 rows of a layer touch disjoint variable nodes (no block row repeats a block
+ * column), so a layer is one parallel step and the reference's row-serial, in-place schedule is reproduced
+ * exactly by running the layers in order with a workgroup barrier in between.
+ *   - a-posteriori LLRs En (int8, 17664 B) live in LDS for the whole launch.  Through a circulant with
+ *     shift s, lane i touches byte (s+i) mod 256 of its block column; its second row touches that byte ^ 128;
+ *   - the two rows of a thread are processed as the two 16-bit halves of packed VALU operations
+ *     (v_pk_sub_i16 / v_pk_min/max / v_perm_b32 as an 8-entry FAID look-up table), which halves the vector
+ *     instruction count per edge;
+ *   - check-to-variable messages are never stored per edge (the reference keeps 70400 bytes per codeword,
+ *     CLDPC.h:123).  A row's outgoing messages are +-c1 on the edge of the first minimum and +-c2 elsewhere:
+ *     8 bytes per row {sign bits, argmin, c1, c2} reproduce every Lmn bit for bit; they
+ *     stream through global memory one layer ahead of use (16 B per lane, coalesced);
+ *   - syndromes are bit-parallel: hard decisions are kept as a bit plane and the parity of 64 rows of a
+ *     layer is the XOR of <= 24 rotated 64-bit windows of it (one circulant per lane, DPP XOR-reduction);
+ *   - the bit-flipping stage is bit-sliced: votes of 64 variable nodes are three rotated windows of the
+ *     parity plane, added and compared with the threshold by boolean word operations.
  *
  * Group-of-32 semantics.  The reference stops a group of 32 codewords only when all 32 are clean
  * (CDecoder_FAID.cpp:616, :6782) and keeps iterating / flipping already-clean lanes meanwhile, which
@@ -37,43 +41,113 @@
 #define SAT_NEG_VAR (-31)
 #define SAT_POS_MSG 7  /* Constants_SSE.h:24 */
 
+/* tables are read through the constant address space so that uniform accesses become scalar loads */
+typedef const __attribute__((address_space(4))) LfDevCode* CCode;
+typedef const __attribute__((address_space(4))) LfDevCfg* CCfg;
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+union Pk { uint32_t u; s2 s; u2 us; };
+__device__ __forceinline__ s2 S(uint32_t x) { Pk v; v.u = x; return v.s; }
+__device__ __forceinline__ u2 US(uint32_t x) { Pk v; v.u = x; return v.us; }
+__device__ __forceinline__ uint32_t U(s2 x) { Pk v; v.s = x; return v.u; }
+__device__ __forceinline__ uint32_t U(u2 x) { Pk v; v.us = x; return v.u; }
+__device__ __forceinline__ s2 pk_max(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s2 pk_min(s2 a, s2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ u2 pk_maxu(u2 a, u2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ u2 pk_minu(u2 a, u2 b) { return __builtin_elementwise_min(a, b); }
+
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ int iclamp(int x, int lo, int hi) { return imin(imax(x, lo), hi); }
 
-/* LDS byte address of the variable node that lane `tid` touches through circulant `ci` */
-__device__ __forceinline__ int vn_addr(uint32_t ci, int tid)
-{
-    return (int)((ci & 0xffu) << 8) + (int)((((ci >> 8) & 0xffu) + (uint32_t)tid) & 0xffu);
-}
-
-/* sum of a wave-uniform per-wave value over the 4 waves of the workgroup */
-__device__ __forceinline__ int block_sum4(int wave_value, int tid, int* sRed)
+/* sum of a wave-uniform per-wave value over the 2 waves of the workgroup */
+__device__ __forceinline__ int block_sum2(int wave_value, int tid, int* sRed)
 {
     if ((tid & 63) == 0) sRed[tid >> 6] = wave_value;
     __syncthreads();
-    int total = sRed[0] + sRed[1] + sRed[2] + sRed[3];
+    const int total = sRed[0] + sRed[1];
     __syncthreads();
     return total;
 }
 
-/* ---- syndrome in front of a layered iteration (CDecoder_FAID.cpp:291-343, CDecoder_OMS.cpp:102-323) -----
- * returns the number of unsatisfied checks of the codeword; pbits bit br = parity of this lane's row in
- * layer br (l_checksum_[br*256 + tid]). */
-__device__ int eval_main(const LfDevCode* __restrict__ c, const int8_t* sEn, int tid, uint32_t& pbits, int* sRed)
+/* XOR over lanes 0..31 of a wave half, result in lane 31 (DPP row shifts + row broadcast, no LDS) */
+__device__ __forceinline__ uint32_t xor_reduce32(uint32_t v)
 {
-    uint32_t pb = 0;
-    int cnt = 0;
-    const int nbr = c->nbr;
-    for (int br = 0; br < nbr; ++br) {
-        const int deg = c->deg[br];
-        int p = 0;
-        for (int j = 0; j < deg; ++j) p ^= (sEn[vn_addr(c->circ[br][j], tid)] > 0) ? 1 : 0;
-        pb |= (uint32_t)p << br;
-        cnt += __popcll(__ballot(p));
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1, 3 */
+    return v;
+}
+
+/* 64 bits starting at bit `o` (mod 256) of a 256-bit block kept as 8 LDS words */
+__device__ __forceinline__ void window64(const uint32_t* blk, uint32_t o, uint32_t& lo, uint32_t& hi)
+{
+    const uint32_t q = o >> 5, r = o & 31u;
+    const uint32_t w0 = blk[q & 7u], w1 = blk[(q + 1u) & 7u], w2 = blk[(q + 2u) & 7u];
+    lo = __builtin_amdgcn_alignbit(w1, w0, r);
+    hi = __builtin_amdgcn_alignbit(w2, w1, r);
+}
+
+/* ---- hard-decision bit planes from En (CDecoder_FAID.cpp:299, :6416-6419; 2B1C :6132-6136) ------------- */
+template <bool WITH_H2>
+__device__ void build_planes(CCode c, const int8_t* sEn, uint32_t* sHard, uint32_t* sHard2, int thr, int tid)
+{
+    const int N = c->n_var;
+    for (int base = 0; base < N; base += LF_T) {
+        const int v = base + tid;
+        const int e = sEn[v];
+        const unsigned long long h = __ballot(e > 0);
+        unsigned long long h2 = 0;
+        if (WITH_H2) h2 = __ballot(e >= thr || e <= -thr);
+        if ((tid & 63) == 0) {
+            const int w = v >> 5;
+            sHard[w] = (uint32_t)h;
+            sHard[w + 1] = (uint32_t)(h >> 32);
+            if (WITH_H2) { sHard2[w] = (uint32_t)h2; sHard2[w + 1] = (uint32_t)(h2 >> 32); }
+        }
     }
-    pbits = pb;
-    return block_sum4(cnt, tid, sRed);
+    __syncthreads();
+}
+
+/* ---- bit-parallel syndrome of a hard-decision plane (CDecoder_FAID.cpp:291-343, :6443-6491) ---------------
+ * Wave w owns rows [64w, 64w+64) and [128+64w, 128+64w+64) of every layer; lane j < deg fetches the two
+ * 64-bit windows that circulant j contributes, the XOR over the lanes is the parity of those 128 rows.
+ * Writes the parity plane sP (bit r = l_checksum_[r]), returns the number of unsatisfied checks; pA / pB get
+ * bit br = parity of this thread's rows tid / tid + 128 in layer br. */
+__device__ int syndrome(CCode c, const LfDevCode* gc, const uint32_t* plane, uint32_t* sP, int tid, uint32_t& pA,
+                        uint32_t& pB, int* sRed)
+{
+    const int w = tid >> 6, lane = tid & 63;
+    const int nbr = c->nbr;
+    uint32_t a = 0, b = 0;
+    int cnt = 0;
+    uint32_t nxt = gc->syn[0][lane & 31]; /* lane-indexed: vector load, one layer ahead */
+    for (int br = 0; br < nbr; ++br) {
+        const uint32_t e = nxt;
+        if (br + 1 < nbr) nxt = gc->syn[br + 1][lane & 31];
+        uint32_t loA = 0, hiA = 0, loB = 0, hiB = 0;
+        if (lane < 32 && e != 0xffffffffu) {
+            const uint32_t* blk = plane + (e >> 8) * 8u;
+            const uint32_t o = ((e & 0xffu) + 64u * (uint32_t)w) & 255u;
+            window64(blk, o, loA, hiA);
+            window64(blk, o ^ 128u, loB, hiB);
+        }
+        loA = xor_reduce32(loA); hiA = xor_reduce32(hiA); loB = xor_reduce32(loB); hiB = xor_reduce32(hiB);
+        const uint32_t rloA = __builtin_amdgcn_readlane(loA, 31), rhiA = __builtin_amdgcn_readlane(hiA, 31);
+        const uint32_t rloB = __builtin_amdgcn_readlane(loB, 31), rhiB = __builtin_amdgcn_readlane(hiB, 31);
+        if (lane == 0) {
+            uint32_t* p = sP + br * 8 + 2 * w;
+            p[0] = rloA; p[1] = rhiA; p[4] = rloB; p[5] = rhiB;
+        }
+        cnt += __popc(rloA) + __popc(rhiA) + __popc(rloB) + __popc(rhiB);
+        const uint32_t selA = lane < 32 ? rloA : rhiA, selB = lane < 32 ? rloB : rhiB;
+        a |= ((selA >> (lane & 31)) & 1u) << br;
+        b |= ((selB >> (lane & 31)) & 1u) << br;
+    }
+    pA = a; pB = b;
+    return block_sum2(cnt, tid, sRed); /* its barriers also publish sP */
 }
 
 /* selective offset of OMS_MODE 1 on one minimum (CDecoder_OMS.cpp:388-425); all operands are int8 in the
@@ -90,13 +164,16 @@ __device__ __forceinline__ int oms_offset(int x, bool window, bool F, int f1, in
     return x;
 }
 
+#define JJ(j) ((uint32_t)(j) | ((uint32_t)(j) << 16))
+
 /* ---- one layered iteration (FAID / 2B1C: CDecoder_FAID.cpp:631-1527; OMS: CDecoder_OMS.cpp:334-743) -----
- * rows: this codeword's compressed messages, [nbr][256] uint2:
- *   .x = bit j: sign of Lmn on edge j (1 = negative) | argmin edge << 24
- *   .y = c1 | c2 << 4      Lmn(edge j) = (j == argmin ? c1 : c2) with that sign */
-template <int METHOD>
-__device__ void main_step(const LfDevCode* __restrict__ c, const LfDevCfg* __restrict__ f, int8_t* sEn,
-                          uint2* __restrict__ rows, int tid, int it, uint32_t pbits, bool lme)
+ * rows: this codeword's compressed messages, [nbr][128] uint4 for the row pair (tid, tid+128); 16-bit halves:
+ *   .x bit j (j < 16), .y bit j-16: raw sign s_j of the V2C on edge j, low half row A, high half row B
+ *   .z per half: argmin edge | c1 << 5 | c2 << 8 | F << 15, F = XOR_all(s) ^ (deg odd)
+ *   Lmn(edge j) = (j == argmin ? c1 : c2), negative iff s_j ^ F */
+template <int METHOD, bool UNIW>
+__device__ void main_step(CCode c, CCfg f, int8_t* sEn, uint4* __restrict__ rows, int tid, int it, uint32_t pA,
+                          uint32_t pB, bool lme)
 {
     const bool fresh = (it == 1); /* no iteration has run yet: every Lmn is still 0, nothing in HBM */
     const int rem = f->max_iter - it; /* nombre_iterations inside the loop body */
@@ -104,149 +181,126 @@ __device__ void main_step(const LfDevCode* __restrict__ c, const LfDevCfg* __res
     const bool window = rem <= f->floor_iter_thresh;
     const int f1 = f->factor_1, f2 = f->factor_2;
     const int nbr = c->nbr;
+    uint32_t llo = f->lut_lo[itx][0], lhi = f->lut_hi[itx][0];
+    uint32_t elo = f->lut_ef_lo[itx][0], ehi = f->lut_ef_hi[itx][0];
 
-    uint2 cur = make_uint2(0u, 0u); /* Lmn = 0 before the first iteration (CDecoder_FAID.cpp:211-214) */
+    uint4 cur = make_uint4(0u, 0u, 0u, 0u); /* Lmn = 0 before the first iteration (CDecoder_FAID.cpp:211-214) */
     if (!fresh) cur = rows[tid];
     for (int br = 0; br < nbr; ++br) {
-        uint2 nxt = make_uint2(0u, 0u);
-        if (!fresh && br + 1 < nbr) nxt = rows[(br + 1) * LF_Z + tid]; /* one layer ahead of use */
+        uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
+        if (!fresh && br + 1 < nbr) nxt = rows[(br + 1) * LF_T + tid]; /* one layer ahead of use */
         const int deg = c->deg[br];
-        const uint32_t negw = cur.x;
-        const int idx_old = (int)(cur.x >> 24);
-        const int c1o = (int)(cur.y & 15u), c2o = (int)((cur.y >> 4) & 15u);
-        const bool pr = (pbits >> br) & 1u;
-        const bool efsel = (METHOD == 5) && window && lme && pr; /* mask_eef, CDecoder_FAID.cpp:713-720 */
+        const uint32_t Fo = U(S(cur.z) >> (s2)(15)); /* 0 / 0xffff per half */
+        const uint32_t XL = cur.x ^ Fo, XH = cur.y ^ Fo;
+        const uint32_t IDXo = cur.z & 0x001f001fu;
+        const u2 C1o = US((cur.z >> 5) & 0x00070007u), C2o = US((cur.z >> 8) & 0x00070007u);
+        const u2 DCo = C2o - C1o;
+        const bool prA = (pA >> br) & 1u, prB = (pB >> br) & 1u;
+        uint32_t efmask = 0; /* mask_eef per row, CDecoder_FAID.cpp:713-720 */
+        if (METHOD == 5 && window && lme) efmask = (prA ? 0x0000ffffu : 0u) | (prB ? 0xffff0000u : 0u);
 
-        uint32_t tw[LF_MAX_DEG / 4] = { 0u, 0u, 0u, 0u, 0u, 0u }; /* V2C values t of the row, one byte each */
-        uint32_t sgn = 0;
-        int min1 = SAT_POS_VAR, min2 = SAT_POS_VAR, jmin = 0;
+        uint32_t y[LF_MAX_DEG];
+        uint32_t sx = 0;
+        u2 k1 = US(0x1fff1fffu), k2 = US(0x1fff1fffu);
 
 #pragma unroll
         for (int j = 0; j < LF_MAX_DEG; ++j) {
             if (j < deg) {
-                const uint32_t ci = c->circ[br][j];
-                const int En = sEn[vn_addr(ci, tid)];
-                const int mag = (j == idx_old) ? c1o : c2o;
-                const int Lmn = ((negw >> j) & 1u) ? -mag : mag;
-                int t = imax(En - Lmn, SAT_NEG_VAR); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
-                int s, m;
+                const uint32_t ci_shift = c->circ[br][j].shift, ci_base = c->circ[br][j].base;
+                const uint32_t adA = (((uint32_t)tid + ci_shift) & 255u) | ci_base;
+                const int eA = sEn[adA], eB = sEn[adA ^ 128u];
+                const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
+                const u2 ne = pk_minu(US(IDXo ^ JJ(j)), (u2)(1));
+                const u2 mag = ne * DCo + C1o;
+                const s2 sm = S(U(US(j < 16 ? XL : XH) << (u2)(15 - (j & 15)))) >> (s2)(15);
+                const s2 Lmn = S(U(mag) ^ U(sm)) - sm;
+                s2 t = pk_max(E - Lmn, (s2)(SAT_NEG_VAR)); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
+                s2 yy;
                 if (METHOD == 1) {
-                    s = t < 0;                                        /* CDecoder_OMS.cpp:372 */
-                    m = imin(t < 0 ? -t : t, SAT_POS_MSG);            /* :374 */
+                    yy = t * (s2)(64) + (s2)(32); /* sign(yy) = (t < 0), CDecoder_OMS.cpp:372 */
                 } else {
-                    t = imin(t, SAT_POS_VAR);                         /* CDecoder_FAID.cpp:672 */
-                    s = ((t != 0) ? t : En) < 0;                      /* sign back-track, :682 */
-                    const int a = imin(t < 0 ? -t : t, SAT_POS_MSG);  /* |t| >= 8 maps through column 7, :783 */
-                    const uint32_t w = (ci >> 16) & 3u;
-                    uint32_t lut = f->lut[itx][w];
-                    if (METHOD == 5) { const uint32_t le = f->lut_ef[itx][w]; lut = efsel ? le : lut; }
-                    m = (int)((lut >> (4 * a)) & 15u);
+                    t = pk_min(t, (s2)(SAT_POS_VAR)); /* CDecoder_FAID.cpp:672 */
+                    yy = t * (s2)(64) + E;            /* sign(yy) = sign of (t != 0 ? t : En): back-track, :682 */
                 }
-                sgn |= (uint32_t)s << j;
-                min2 = imin(min2, imax(min1, m)); /* VECTOR_MIN_2 with the old min1 */
-                jmin = (m < min1) ? j : jmin;
-                min1 = imin(min1, m);
-                tw[j >> 2] |= ((uint32_t)t & 0xffu) << ((j & 3) * 8);
+                y[j] = U(yy);
+                sx ^= U(yy);
+                const s2 a = pk_min(pk_max(t, (s2)(0) - t), (s2)(SAT_POS_MSG)); /* |t| >= 8 maps through column 7 */
+                uint32_t m;
+                if (METHOD == 1) {
+                    m = U(a); /* CDecoder_OMS.cpp:374 */
+                } else {
+                    if (!UNIW) {
+                        const uint32_t wc = (ci_shift >> 16) & 3u;
+                        llo = f->lut_lo[itx][wc]; lhi = f->lut_hi[itx][wc];
+                        if (METHOD == 5) { elo = f->lut_ef_lo[itx][wc]; ehi = f->lut_ef_hi[itx][wc]; }
+                    }
+                    const uint32_t sel = U(a) | 0x0c000c00u;
+                    m = __builtin_amdgcn_perm(lhi, llo, sel);
+                    if (METHOD == 5) {
+                        const uint32_t me = __builtin_amdgcn_perm(ehi, elo, sel);
+                        m = (m & ~efmask) | (me & efmask);
+                    }
+                }
+                const u2 key = US((m << 8) | JJ(j));
+                k2 = pk_minu(k2, pk_maxu(k1, key)); /* VECTOR_MIN_2 with the old min1 */
+                k1 = pk_minu(k1, key);
             }
         }
 
-        int c1, c2;
+        const u2 min1 = k1 >> (u2)(8), min2 = k2 >> (u2)(8);
+        const uint32_t JM = U(k1) & 0x00ff00ffu;
+        u2 C1n, C2n;
         if (METHOD == 1) {
-            const bool F = pr && lme;
-            c1 = imin(oms_offset(min2, window, F, f1, f2), SAT_POS_MSG); /* cste_1, CDecoder_OMS.cpp:431 */
-            c2 = imin(oms_offset(min1, window, F, f1, f2), SAT_POS_MSG); /* cste_2 */
+            const bool FA = prA && lme, FB = prB && lme;
+            const int a1 = imin(oms_offset(min2.x, window, FA, f1, f2), SAT_POS_MSG); /* cste_1, CDecoder_OMS.cpp:431 */
+            const int a2 = imin(oms_offset(min1.x, window, FA, f1, f2), SAT_POS_MSG); /* cste_2 */
+            const int b1 = imin(oms_offset(min2.y, window, FB, f1, f2), SAT_POS_MSG);
+            const int b2 = imin(oms_offset(min1.y, window, FB, f1, f2), SAT_POS_MSG);
+            C1n = US((uint32_t)(a1 & 0xffff) | ((uint32_t)b1 << 16));
+            C2n = US((uint32_t)(a2 & 0xffff) | ((uint32_t)b2 << 16));
         } else {
-            c1 = imin(min2, SAT_POS_MSG); /* CDecoder_FAID.cpp:865-866, offset 0 */
-            c2 = imin(min1, SAT_POS_MSG);
+            C1n = pk_minu(min2, (u2)(SAT_POS_MSG)); /* CDecoder_FAID.cpp:865-866, offset 0 */
+            C2n = pk_minu(min1, (u2)(SAT_POS_MSG));
         }
+        const u2 DCn = C2n - C1n;
         /* sign of the new message on edge j: XOR of all signs ^ (deg odd) ^ own sign
          * (the 0xC0 / 0x40 constants of CDecoder_FAID.cpp:902-906 fed to _mm256_sign_epi8) */
-        const uint32_t flip = ((__popc(sgn) ^ deg) & 1) ? 0xffffffffu : 0u;
-        const uint32_t negn = (sgn ^ flip) & ((1u << deg) - 1u);
+        const uint32_t Fn = U(S(sx) >> (s2)(15)) ^ ((deg & 1) ? 0xffffffffu : 0u);
 
+        uint32_t nXL = 0, nXH = 0;
 #pragma unroll
         for (int j = 0; j < LF_MAX_DEG; ++j) {
             if (j < deg) {
-                const uint32_t ci = c->circ[br][j];
-                const int t = (int)(int8_t)(tw[j >> 2] >> ((j & 3) * 8));
-                const int mag = (j == jmin) ? c1 : c2;
-                const int Lmn = ((negn >> j) & 1u) ? -mag : mag;
-                sEn[vn_addr(ci, tid)] = (int8_t)iclamp(t + Lmn, SAT_NEG_VAR, SAT_POS_VAR); /* :919-920 */
+                const uint32_t ci_shift = c->circ[br][j].shift, ci_base = c->circ[br][j].base;
+                const uint32_t adA = (((uint32_t)tid + ci_shift) & 255u) | ci_base;
+                const s2 yy = S(y[j]);
+                const s2 t = (METHOD == 1) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
+                const u2 ne = pk_minu(US(JM ^ JJ(j)), (u2)(1));
+                const u2 mag = ne * DCn + C1n;
+                const uint32_t sm = U(yy >> (s2)(15)) ^ Fn;
+                const s2 Lmn = S(U(mag) ^ sm) - S(sm);
+                const s2 en = pk_min(pk_max(t + Lmn, (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
+                const uint32_t sb = U(US(U(yy)) >> (u2)(15));
+                if (j < 16) nXL |= sb << j; else nXH |= sb << (j - 16);
+                sEn[adA] = (int8_t)en.x;
+                sEn[adA ^ 128u] = (int8_t)en.y;
             }
         }
-        rows[br * LF_Z + tid] = make_uint2(negn | ((uint32_t)jmin << 24), (uint32_t)c1 | ((uint32_t)c2 << 4));
+        rows[br * LF_T + tid] = make_uint4(nXL, nXH, JM | (U(C1n) << 5) | (U(C2n) << 8) | (Fn & 0x80008000u), 0u);
         __syncthreads(); /* the next layer reads what this one wrote */
         cur = nxt;
     }
 }
 
-/* ---- bit-flipping stage: layout of the LDS overlay -------------------------------------------------- */
-/* [0, nw) hard_llr   [nw, 2nw) hard_ch   [2nw, 3nw) hard2_llr   [3nw, 3nw + pw) l_checksum_ bits */
-
-/* hard decisions from En, straight to the codeword's HBM bit planes (CDecoder_FAID.cpp:6416-6419,
- * CDecoder_FAID_2B1C.cpp:6132-6136) */
-__device__ void bf_init_planes(const LfDevCode* __restrict__ c, const LfDevCfg* __restrict__ f, const int8_t* sEn,
-                               uint32_t* __restrict__ gbits, int tid)
-{
-    const int nw = c->n_words;
-    const int thr = f->hard2_thr;
-    for (int base = 0; base < c->n_var; base += LF_Z) {
-        const int v = base + tid;
-        int e = (v < c->n_var) ? (int)sEn[v] : 0;
-        const unsigned long long h = __ballot(e > 0);
-        const unsigned long long h2 = __ballot(e >= thr || e <= -thr);
-        if ((tid & 63) == 0 && v < c->n_var) {
-            const int w = v >> 5;
-            gbits[w] = (uint32_t)h;
-            gbits[nw + w] = (uint32_t)h;
-            gbits[2 * nw + w] = (uint32_t)h2;
-            if (w + 1 < nw) {
-                gbits[w + 1] = (uint32_t)(h >> 32);
-                gbits[nw + w + 1] = (uint32_t)(h >> 32);
-                gbits[2 * nw + w + 1] = (uint32_t)(h2 >> 32);
-            }
-        }
-    }
-}
-
+/* ---- bit-flipping iteration after a dirty syndrome (CDecoder_FAID.cpp:6787-6845, :7084-7086;
+ *      CDecoder_FAID_2B1C.cpp:6801-6814) --------------------------------------------------------------- */
 __device__ __forceinline__ int bit_of(const uint32_t* words, int v) { return (int)((words[v >> 5] >> (v & 31)) & 1u); }
 
-/* syndrome on the hard decisions (CDecoder_FAID.cpp:6443-6491): parity bits into the LDS plane, returns
- * the number of unsatisfied checks */
-__device__ int eval_bf(const LfDevCode* __restrict__ c, uint32_t* sBits, int tid, int* sRed)
-{
-    const int nw = c->n_words;
-    uint32_t* sP = sBits + 3 * nw;
-    int cnt = 0;
-    const int nbr = c->nbr;
-    for (int br = 0; br < nbr; ++br) {
-        const int deg = c->deg[br];
-        int p = 0;
-        for (int j = 0; j < deg; ++j) p ^= bit_of(sBits, vn_addr(c->circ[br][j], tid));
-        const unsigned long long b = __ballot(p);
-        cnt += __popcll(b);
-        if ((tid & 63) == 0) {
-            const int w = (br * LF_Z + tid) >> 5;
-            sP[w] = (uint32_t)b;
-            sP[w + 1] = (uint32_t)(b >> 32);
-        }
-    }
-    return block_sum4(cnt, tid, sRed); /* its barriers also publish sP */
-}
-
-/* one bit-flipping iteration after a dirty syndrome (CDecoder_FAID.cpp:6787-6845, :7084-7086;
- * CDecoder_FAID_2B1C.cpp:6801-6814) */
 template <int METHOD>
-__device__ void bf_step(const LfDevCode* __restrict__ c, const LfDevCfg* __restrict__ f, uint32_t* sBits, int tid,
-                        LfLaneState& ls, int* sRed)
+__device__ void bf_step(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, const uint32_t* sHard0, uint32_t* sHard2,
+                        const uint32_t* sP, int tid, LfLaneState& ls, int* sRed)
 {
-    const int nw = c->n_words;
-    uint32_t* sHard = sBits;
-    const uint32_t* sHard0 = sBits + nw;
-    uint32_t* sHard2 = sBits + 2 * nw;
-    const uint32_t* sP = sBits + 3 * nw;
     const int W = f->W;
-
     /* threshold state machine on int8 lanes (CDecoder_FAID.cpp:6787-6799) */
     int Th = ls.Th, l0 = ls.l0, l1 = ls.l1;
     if (!ls.t) Th = imax(Th - f->delta, -128);
@@ -258,62 +312,103 @@ __device__ void bf_step(const LfDevCode* __restrict__ c, const LfDevCfg* __restr
     Th = imax(Th, 1);
     const bool big = Th >= (int)(int8_t)W; /* mask_big_jump, 2B1C only */
     const int alpha = (int8_t)f->alpha;
-
     int any = 0;
-    const int nbc = c->nbc;
-    for (int cb = 0; cb < nbc; ++cb) {
-        if (c->col_weight[cb] != W) continue; /* VN_weight_[v] == REGULAR_COL_WEIGHT, :6806 */
-        const int v = cb * LF_Z + tid;
-        int vote = 0;
-        for (int k = 0; k < W; ++k) {
-            const uint32_t cc = c->colcirc[cb][k];
-            const int r = (int)((cc & 0xffu) << 8) + (int)(((uint32_t)tid - ((cc >> 8) & 0xffu)) & 0xffu);
-            vote += bit_of(sP, r);
-        }
-        const int flipped = bit_of(sHard, v) ^ bit_of(sHard0, v);
-        const int fl = (imin(vote + (flipped ? alpha : 0), 127) >= Th) ? 1 : 0;
-        const unsigned long long fm = __ballot(fl);
-        any |= (fm != 0ull);
-        if ((tid & 63) == 0) {
-            const int w = v >> 5;
+
+    if (f->bf_fast) {
+        /* bit-sliced: one (weight-3 block column, 64-VN window) per lane */
+        const int units = c->n_wcols * 4;
+        for (int u = tid; u < units; u += LF_T) {
+            const int cb = gc->wcol[u >> 2];
+            const uint32_t win = (uint32_t)(u & 3);
+            uint32_t plo[3], phi[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t cc = gc->colcirc[cb][k];
+                window64(sP + (cc & 0xffu) * 8u, (64u * win - ((cc >> 8) & 0xffu)) & 255u, plo[k], phi[k]);
+            }
+            const int w0 = cb * 8 + 2 * (int)win;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint32_t m = (uint32_t)(fm >> (32 * h));
+                const uint32_t p1 = h ? phi[0] : plo[0], p2 = h ? phi[1] : plo[1], p3 = h ? phi[2] : plo[2];
+                const uint32_t hd = sHard[w0 + h];
+                const uint32_t fl = alpha ? (hd ^ sHard0[w0 + h]) : 0u; /* already flipped once: +alpha */
+                const uint32_t s0 = p1 ^ p2 ^ p3, cy = (p1 & p2) | (p1 & p3) | (p2 & p3);
+                uint32_t m;
+                if (Th <= 1) m = s0 | cy | fl;          /* votes + fl >= 1 */
+                else if (Th == 2) m = cy | (s0 & fl);
+                else if (Th == 3) m = cy & (s0 | fl);
+                else if (Th == 4) m = cy & s0 & fl;
+                else m = 0u;
+                any |= (m != 0u);
                 if (METHOD == 5) {
-                    const uint32_t h2 = sHard2[w + h];
-                    if (big) { sHard[w + h] ^= m; sHard2[w + h] = h2 ^ m; }
-                    else { sHard[w + h] ^= m & ~h2; sHard2[w + h] = h2 & ~m; }
+                    const uint32_t h2 = sHard2[w0 + h];
+                    if (big) { sHard[w0 + h] = hd ^ m; sHard2[w0 + h] = h2 ^ m; }
+                    else { sHard[w0 + h] = hd ^ (m & ~h2); sHard2[w0 + h] = h2 & ~m; }
                 } else {
-                    sHard[w + h] ^= m;
+                    sHard[w0 + h] = hd ^ m;
+                }
+            }
+        }
+    } else {
+        /* generic column weight / alpha: one variable node per lane and step */
+        const int nbc = c->nbc;
+        for (int cb = 0; cb < nbc; ++cb) {
+            if (c->col_weight[cb] != W) continue; /* VN_weight_[v] == REGULAR_COL_WEIGHT, :6806 */
+            for (int half = 0; half < 2; ++half) {
+                const int x = tid + half * LF_T;
+                const int v = cb * LF_Z + x;
+                int vote = 0;
+                for (int k = 0; k < W; ++k) {
+                    const uint32_t cc = gc->colcirc[cb][k];
+                    vote += bit_of(sP, (int)((cc & 0xffu) << 8) + (int)(((uint32_t)x - ((cc >> 8) & 0xffu)) & 0xffu));
+                }
+                const int flipped = bit_of(sHard, v) ^ bit_of(sHard0, v);
+                const int fl = (imin(vote + (flipped ? alpha : 0), 127) >= Th) ? 1 : 0;
+                const unsigned long long fm = __ballot(fl);
+                any |= (fm != 0ull);
+                if ((tid & 63) == 0) {
+                    const int w = v >> 5;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t m = (uint32_t)(fm >> (32 * h));
+                        if (METHOD == 5) {
+                            const uint32_t h2 = sHard2[w + h];
+                            if (big) { sHard[w + h] ^= m; sHard2[w + h] = h2 ^ m; }
+                            else { sHard[w + h] ^= m & ~h2; sHard2[w + h] = h2 & ~m; }
+                        } else {
+                            sHard[w + h] ^= m;
+                        }
+                    }
                 }
             }
         }
     }
     ls.Th = Th; ls.l0 = l0; ls.l1 = l1;
-    ls.t = block_sum4(any, tid, sRed) != 0; /* barriers also order the plane updates before the next syndrome */
+    const unsigned long long anyw = __ballot(any);
+    ls.t = block_sum2(anyw != 0ull ? 1 : 0, tid, sRed) != 0; /* barriers also order the plane updates */
 }
 
 /* ---- the decode kernel: one workgroup per codeword ---------------------------------------------------- */
-template <int METHOD>
-__global__ __launch_bounds__(LF_Z) void lnsfaid_decode_kernel(LfKernelArgs a)
+template <int METHOD, bool UNIW>
+__global__ __launch_bounds__(LF_T) void lnsfaid_decode_kernel(LfKernelArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const LfDevCode* __restrict__ c = a.code;
-    const LfDevCfg* __restrict__ f = a.cfg;
+    CCode c = (CCode)a.code;
+    CCfg f = (CCfg)a.cfg;
     const int tid = (int)threadIdx.x;
     const int cw = (int)blockIdx.x;
-    const int N = c->n_var, M = c->n_check, K = c->k_info, nw = c->n_words;
-    const int lds_main = (N + 15) & ~15;
-    const int lds_bf = ((3 * nw + c->p_words + 2) * 4 + 15) & ~15;
-    const int lds_state = lds_main > lds_bf ? lds_main : lds_bf;
+    const int N = c->n_var, M = c->n_check, K = c->k_info, nw = c->n_words, pw = c->p_words;
     int8_t* sEn = (int8_t*)smem;
-    uint32_t* sBits = (uint32_t*)smem;
-    int* sStat = (int*)(smem + lds_state);
+    uint32_t* sHard0 = (uint32_t*)smem; /* bit-flipping stage: hard_ch overlays the dead En */
+    uint32_t* sHard = (uint32_t*)(smem + lf_lds_off_hard(N));
+    uint32_t* sHard2 = (uint32_t*)(smem + lf_lds_off_hard2(N, nw));
+    uint32_t* sP = (uint32_t*)(smem + lf_lds_off_p(N, nw));
+    int* sStat = (int*)(smem + lf_lds_off_stat(N, nw, pw));
     int* sRed = sStat + LNSFAID_GROUP;
 
     const int max_iter = f->max_iter, max_bf = f->max_bf;
-    const int t_bf0 = max_iter + 1;      /* first bit-flipping decision point */
-    const int t_end = t_bf0 + max_bf;    /* both loops exhausted               */
+    const int t_bf0 = max_iter + 1;   /* first bit-flipping decision point */
+    const int t_end = t_bf0 + max_bf; /* both loops exhausted               */
 
     const int my_status = a.status_cur[cw];
     if (my_status & LF_DONE) { /* uniform exit */
@@ -321,7 +416,7 @@ __global__ __launch_bounds__(LF_Z) void lnsfaid_decode_kernel(LfKernelArgs a)
         return;
     }
     /* snapshot of the 32 lanes of this group */
-    const int g = cw >> 5, lane = cw & 31;
+    const int g = cw >> 5, lane_in_group = cw & 31;
     if (tid < LNSFAID_GROUP) sStat[tid] = a.status_cur[g * LNSFAID_GROUP + tid];
     __syncthreads();
     int kmax = 0, all_same = 1;
@@ -333,7 +428,7 @@ __global__ __launch_bounds__(LF_Z) void lnsfaid_decode_kernel(LfKernelArgs a)
     int prog = my_status & LF_PROG_MASK;
 
     int8_t* g_en = a.st_en + (size_t)cw * (size_t)N;
-    uint2* g_rows = a.st_rows + (size_t)cw * (size_t)(c->nbr * LF_Z);
+    uint4* g_rows = a.st_rows + (size_t)cw * (size_t)(c->nbr * LF_T);
     uint32_t* g_bits = a.st_bits + (size_t)cw * (size_t)(3 * nw);
     int8_t* g_out = a.decoded + (size_t)cw * (size_t)N;
 
@@ -351,31 +446,22 @@ __global__ __launch_bounds__(LF_Z) void lnsfaid_decode_kernel(LfKernelArgs a)
         /* input staging (CDecoder_FAID.cpp:217-255): lane l of group g is information row l of the
          * [32][K] block followed by parity row l of the [32][M] block; erase the punctured tail */
         const int8_t* gi = a.fix_input + (size_t)g * (size_t)LNSFAID_GROUP * (size_t)N;
-        const uint32_t* src_i = (const uint32_t*)(gi + (size_t)lane * (size_t)K);
-        const uint32_t* src_p = (const uint32_t*)(gi + (size_t)LNSFAID_GROUP * (size_t)K + (size_t)lane * (size_t)M);
+        const uint32_t* src_i = (const uint32_t*)(gi + (size_t)lane_in_group * (size_t)K);
+        const uint32_t* src_p = (const uint32_t*)(gi + (size_t)LNSFAID_GROUP * (size_t)K + (size_t)lane_in_group * (size_t)M);
         uint32_t* dst = (uint32_t*)sEn;
-        for (int i = tid; i < (K >> 2); i += LF_Z) dst[i] = src_i[i];
-        for (int i = tid; i < (M >> 2); i += LF_Z) dst[(K >> 2) + i] = src_p[i];
+        for (int i = tid; i < (K >> 2); i += LF_T) dst[i] = src_i[i];
+        for (int i = tid; i < (M >> 2); i += LF_T) dst[(K >> 2) + i] = src_p[i];
         __syncthreads();
-        for (int i = tid; i < c->puncture_tail; i += LF_Z) sEn[N - 1 - i] = 0;
+        for (int i = tid; i < c->puncture_tail; i += LF_T) sEn[N - 1 - i] = 0;
         __syncthreads();
         prog = 1;
-        in_bf = max_bf > 0 && prog >= t_bf0;
-        if (in_bf) { /* max_iter == 0: straight to the bit-flipping stage */
-            bf_init_planes(c, f, sEn, g_bits, tid);
-            __threadfence_block();
-            __syncthreads();
-            for (int i = tid; i < 3 * nw; i += LF_Z) sBits[i] = g_bits[i];
-            ls.Th = (int8_t)f->W; ls.l0 = 0; ls.l1 = 0; ls.t = 1;
-            __syncthreads();
-        }
     } else if (!in_bf) {
         const uint32_t* src = (const uint32_t*)g_en;
         uint32_t* dst = (uint32_t*)sEn;
-        for (int i = tid; i < (N >> 2); i += LF_Z) dst[i] = src[i];
+        for (int i = tid; i < (N >> 2); i += LF_T) dst[i] = src[i];
         __syncthreads();
     } else {
-        for (int i = tid; i < 3 * nw; i += LF_Z) sBits[i] = g_bits[i];
+        for (int i = tid; i < nw; i += LF_T) { sHard[i] = g_bits[i]; sHard0[i] = g_bits[nw + i]; sHard2[i] = g_bits[2 * nw + i]; }
         ls = a.st_lane[cw];
         __syncthreads();
     }
@@ -386,29 +472,28 @@ __global__ __launch_bounds__(LF_Z) void lnsfaid_decode_kernel(LfKernelArgs a)
     if (!group_stop) {
         for (;;) {
             if (prog >= t_end) break; /* loops exhausted (also OMS after max_iter iterations) */
+            if (max_bf > 0 && prog >= t_bf0 && !in_bf) {
+                /* the layered loop ran out: enter the bit-flipping stage (CDecoder_FAID.cpp:6411-6428) */
+                build_planes<METHOD == 5>(c, sEn, sHard, sHard2, f->hard2_thr, tid);
+                for (int i = tid; i < nw; i += LF_T) sHard0[i] = sHard[i]; /* En is dead from here on */
+                ls.Th = (int8_t)f->W; ls.l0 = 0; ls.l1 = 0; ls.t = 1;
+                in_bf = true;
+                __syncthreads();
+            }
+            uint32_t pA, pB;
             if (!in_bf) {
-                uint32_t pbits;
-                const int unsat = eval_main(c, sEn, tid, pbits, sRed);
+                build_planes<false>(c, sEn, sHard, sHard2, 0, tid);
+                const int unsat = syndrome(c, a.code, sHard, sP, tid, pA, pB, sRed);
                 if (unsat == 0 && prog >= kmax) break; /* clean on the group's front: park */
                 bool lme;
                 if (METHOD == 1) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
                 else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
-                main_step<METHOD>(c, f, sEn, g_rows, tid, prog, pbits, lme);
+                main_step<METHOD, UNIW>(c, f, sEn, g_rows, tid, prog, pA, pB, lme);
                 prog++;
-                if (prog == t_bf0 && max_bf > 0) {
-                    /* the layered loop ran out: enter the bit-flipping stage */
-                    bf_init_planes(c, f, sEn, g_bits, tid);
-                    __threadfence_block();
-                    __syncthreads();
-                    for (int i = tid; i < 3 * nw; i += LF_Z) sBits[i] = g_bits[i];
-                    ls.Th = (int8_t)f->W; ls.l0 = 0; ls.l1 = 0; ls.t = 1;
-                    in_bf = true;
-                    __syncthreads();
-                }
             } else {
-                const int unsat = eval_bf(c, sBits, tid, sRed);
+                const int unsat = syndrome(c, a.code, sHard, sP, tid, pA, pB, sRed);
                 if (unsat == 0 && prog >= kmax) break;
-                bf_step<METHOD>(c, f, sBits, tid, ls, sRed);
+                bf_step<METHOD>(c, f, a.code, sHard, sHard0, sHard2, sP, tid, ls, sRed);
                 prog++;
             }
         }
@@ -419,7 +504,7 @@ __global__ __launch_bounds__(LF_Z) void lnsfaid_decode_kernel(LfKernelArgs a)
         /* decodedBits[l][v] = hard decision (CDecoder_FAID.cpp:7091-7102, CDecoder_OMS.cpp:2966-2967) */
         uint32_t* out32 = (uint32_t*)g_out;
         if (!in_bf) {
-            for (int i = tid; i < (N >> 2); i += LF_Z) {
+            for (int i = tid; i < (N >> 2); i += LF_T) {
                 const uint32_t e4 = ((const uint32_t*)sEn)[i];
                 uint32_t o = 0;
 #pragma unroll
@@ -427,14 +512,14 @@ __global__ __launch_bounds__(LF_Z) void lnsfaid_decode_kernel(LfKernelArgs a)
                 out32[i] = o;
             }
         } else {
-            for (int i = tid; i < (N >> 2); i += LF_Z) {
-                const uint32_t bits = (sBits[i >> 3] >> ((i & 7) * 4)) & 15u;
+            for (int i = tid; i < (N >> 2); i += LF_T) {
+                const uint32_t bits = (sHard[i >> 3] >> ((i & 7) * 4)) & 15u;
                 out32[i] = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
             }
         }
         if (tid == 0) {
             a.status_next[cw] = prog | LF_DONE;
-            if (a.stats && lane == 0) {
+            if (a.stats && lane_in_group == 0) {
                 lnsfaid_group_stats st;
                 st.iterations = prog <= max_iter ? prog - 1 : max_iter;
                 st.bf_iterations = prog <= max_iter ? 0 : prog - t_bf0;
@@ -446,9 +531,9 @@ __global__ __launch_bounds__(LF_Z) void lnsfaid_decode_kernel(LfKernelArgs a)
         if (!in_bf) {
             const uint32_t* src = (const uint32_t*)sEn;
             uint32_t* dst = (uint32_t*)g_en;
-            for (int i = tid; i < (N >> 2); i += LF_Z) dst[i] = src[i];
+            for (int i = tid; i < (N >> 2); i += LF_T) dst[i] = src[i];
         } else {
-            for (int i = tid; i < 3 * nw; i += LF_Z) g_bits[i] = sBits[i];
+            for (int i = tid; i < nw; i += LF_T) { g_bits[i] = sHard[i]; g_bits[nw + i] = sHard0[i]; g_bits[2 * nw + i] = sHard2[i]; }
             if (tid == 0) a.st_lane[cw] = ls;
         }
         if (tid == 0) { a.status_next[cw] = prog; atomicAdd(a.remaining, 1u); }
@@ -456,17 +541,22 @@ __global__ __launch_bounds__(LF_Z) void lnsfaid_decode_kernel(LfKernelArgs a)
 }
 
 /* ---- CalculateErrors (CLDPC.cpp:4842-4876): one workgroup per frame ----------------------------------- */
-__global__ __launch_bounds__(LF_Z) void lnsfaid_count_errors_kernel(const int8_t* __restrict__ decoded,
-                                                                    const int8_t* __restrict__ input_bits, int n_var,
-                                                                    int k_info, unsigned long long* __restrict__ out)
+__device__ __forceinline__ int nonzero_bytes(uint32_t x)
+{
+    return __popc((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);
+}
+
+__global__ __launch_bounds__(256) void lnsfaid_count_errors_kernel(const int8_t* __restrict__ decoded,
+                                                                   const int8_t* __restrict__ input_bits, int n_var,
+                                                                   int k_info, unsigned long long* __restrict__ out)
 {
     __shared__ int sRed[4];
     const int tid = (int)threadIdx.x;
     const size_t cw = blockIdx.x;
-    const int8_t* d = decoded + cw * (size_t)n_var;
-    const int8_t* r = input_bits ? input_bits + cw * (size_t)k_info : nullptr;
+    const uint32_t* d = (const uint32_t*)(decoded + cw * (size_t)n_var);
+    const uint32_t* r = input_bits ? (const uint32_t*)(input_bits + cw * (size_t)k_info) : nullptr;
     int cnt = 0;
-    for (int j = tid; j < k_info; j += LF_Z) cnt += (d[j] != (r ? r[j] : (int8_t)0)) ? 1 : 0;
+    for (int j = tid; j < (k_info >> 2); j += 256) cnt += nonzero_bytes(d[j] ^ (r ? r[j] : 0u));
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
     if ((tid & 63) == 0) sRed[tid >> 6] = cnt;
     __syncthreads();
@@ -482,22 +572,30 @@ __global__ __launch_bounds__(LF_Z) void lnsfaid_count_errors_kernel(const int8_t
 }
 
 /* ---- launchers (called from lnsfaid_capi.hip) ---------------------------------------------------------- */
-extern "C" hipError_t lf_launch_decode(int method, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream)
+template <int METHOD>
+static hipError_t launch_method(bool uniw, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream)
 {
-    const dim3 grid((unsigned)args->n_cw), block(LF_Z);
+    const dim3 grid((unsigned)args->n_cw), block(LF_T);
+    if (uniw) hipLaunchKernelGGL((lnsfaid_decode_kernel<METHOD, true>), grid, block, lds_bytes, stream, *args);
+    else hipLaunchKernelGGL((lnsfaid_decode_kernel<METHOD, false>), grid, block, lds_bytes, stream, *args);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t lf_launch_decode(int method, int uniform_w, const LfKernelArgs* args, size_t lds_bytes,
+                                       hipStream_t stream)
+{
     switch (method) {
-    case 1: hipLaunchKernelGGL(lnsfaid_decode_kernel<1>, grid, block, lds_bytes, stream, *args); break;
-    case 2: hipLaunchKernelGGL(lnsfaid_decode_kernel<2>, grid, block, lds_bytes, stream, *args); break;
-    case 5: hipLaunchKernelGGL(lnsfaid_decode_kernel<5>, grid, block, lds_bytes, stream, *args); break;
+    case 1: return launch_method<1>(true, args, lds_bytes, stream); /* OMS has no look-up table */
+    case 2: return launch_method<2>(uniform_w != 0, args, lds_bytes, stream);
+    case 5: return launch_method<5>(uniform_w != 0, args, lds_bytes, stream);
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 extern "C" hipError_t lf_launch_count_errors(const int8_t* decoded, const int8_t* input_bits, int n_var, int k_info,
                                              size_t n_cw, unsigned long long* out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(lnsfaid_count_errors_kernel, dim3((unsigned)n_cw), dim3(LF_Z), 0, stream, decoded, input_bits,
+    hipLaunchKernelGGL(lnsfaid_count_errors_kernel, dim3((unsigned)n_cw), dim3(256), 0, stream, decoded, input_bits,
                        n_var, k_info, out);
     return hipGetLastError();
 }
