@@ -96,8 +96,7 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
             const int cb = row0[j] / Z, sh = row0[j] % Z;
             if (row0[j] >= N || cb <= prev_cb) return LNSFAID_E_CODE; /* ascending, no block column twice */
             prev_cb = cb;
-            out->circ[br][j].shift = (uint32_t)sh;
-            out->circ[br][j].base = (uint32_t)cb * (uint32_t)Z;
+            out->circ[br][j].sb = (uint32_t)cb * (uint32_t)Z + (uint32_t)sh;
             out->syn[br][j] = (uint32_t)sh | ((uint32_t)cb << 8);
             if (out->col_weight[cb] >= LF_MAX_COLW) return LNSFAID_E_CODE;
             out->colcirc[cb][out->col_weight[cb]++] = (uint32_t)br | ((uint32_t)sh << 8);
@@ -105,7 +104,8 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
         for (int i = 0; i < Z; ++i) {
             if (row_deg[(size_t)br * Z + i] != deg) return LNSFAID_E_CODE;
             for (int j = 0; j < deg; ++j) {
-                const int want = (int)out->circ[br][j].base + (int)((out->circ[br][j].shift + (uint32_t)i) % (uint32_t)Z);
+                const uint32_t sb = out->circ[br][j].sb;
+                const int want = (int)(sb / (uint32_t)Z * (uint32_t)Z + (sb % (uint32_t)Z + (uint32_t)i) % (uint32_t)Z);
                 if (code->pos_vn[e + (size_t)i * deg + j] != want) return LNSFAID_E_CODE; /* not quasi-cyclic */
             }
         }
@@ -113,7 +113,7 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
     }
     for (int br = 0; br < nbr; ++br)
         for (int j = 0; j < out->deg[br]; ++j)
-            out->circ[br][j].shift |= (uint32_t)weight_class(out->col_weight[out->circ[br][j].base / (uint32_t)Z]) << 16;
+            out->circ[br][j].wclass = (uint32_t)weight_class(out->col_weight[out->circ[br][j].sb / (uint32_t)Z]);
     out->n_var = N; out->n_check = M; out->k_info = K; out->nbr = nbr; out->nbc = nbc;
     out->puncture_tail = code->puncture_tail;
     out->n_words = N / 32; out->p_words = M / 32;

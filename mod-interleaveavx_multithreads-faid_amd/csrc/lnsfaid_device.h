@@ -20,8 +20,8 @@
 #define LF_PROG_MASK 0x0fffffff
 
 struct LfCirc {
-    uint32_t shift; /* circulant shift | weight class << 16             */
-    uint32_t base;  /* block column * 256 = LDS byte offset of the block */
+    uint32_t sb;     /* block column * 256 + circulant shift: LDS byte offset of row 0's variable node */
+    uint32_t wclass; /* weight class 0..3 of the block column (V2C_map row)                            */
 };
 
 /* Quasi-cyclic view of the reference's PosNoeudsVariable table.  Uniformly indexed fields are read with
@@ -68,13 +68,18 @@ struct LfKernelArgs {
     int32_t n_cw;
 };
 
-/* dynamic LDS carve-up, shared by host (size) and device (offsets) */
+/* dynamic LDS carve-up, shared by host (size) and device (offsets):
+ *   [0, N)        En (int8).  In the bit-flipping stage En is dead and the same bytes hold
+ *                 hard_ch  at [0, 4*n_words) and hard2 at [4*n_words, 8*n_words)
+ *   off_hard      hard-decision bit plane, n_words words
+ *   off_p         parity plane l_checksum_, p_words (+2) words
+ *   off_stat      32 status words of the group + reduction scratch
+ * 50G-PON: 17664 + 2208 + 392 + 160 = 20424 B <= 20480 B, i.e. 8 workgroups per CU. */
 static inline __host__ __device__ uint32_t lf_lds_off_hard(int n_var) { return ((uint32_t)n_var + 15u) & ~15u; }
-static inline __host__ __device__ uint32_t lf_lds_off_hard2(int n_var, int n_words) { return lf_lds_off_hard(n_var) + (uint32_t)n_words * 4u; }
-static inline __host__ __device__ uint32_t lf_lds_off_p(int n_var, int n_words) { return lf_lds_off_hard2(n_var, n_words) + (uint32_t)n_words * 4u; }
+static inline __host__ __device__ uint32_t lf_lds_off_p(int n_var, int n_words) { return lf_lds_off_hard(n_var) + (uint32_t)n_words * 4u; }
 static inline __host__ __device__ uint32_t lf_lds_off_stat(int n_var, int n_words, int p_words)
 {
-    return (lf_lds_off_p(n_var, n_words) + ((uint32_t)p_words + 2u) * 4u + 15u) & ~15u;
+    return (lf_lds_off_p(n_var, n_words) + ((uint32_t)p_words + 2u) * 4u + 7u) & ~7u;
 }
 static inline __host__ __device__ uint32_t lf_lds_bytes(int n_var, int n_words, int p_words)
 {

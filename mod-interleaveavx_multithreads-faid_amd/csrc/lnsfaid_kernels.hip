@@ -57,6 +57,15 @@ __device__ __forceinline__ s2 pk_min(s2 a, s2 b) { return __builtin_elementwise_
 __device__ __forceinline__ u2 pk_maxu(u2 a, u2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ u2 pk_minu(u2 a, u2 b) { return __builtin_elementwise_min(a, b); }
 
+/* a * b + c on both 16-bit halves in ONE instruction (the compiler turns the 0/1 multiply into two
+ * compare + select pairs otherwise) */
+__device__ __forceinline__ u2 pk_mad(u2 a, u2 b, u2 c)
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(U(a)), "v"(U(b)), "v"(U(c)));
+    return US(r);
+}
+
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
@@ -90,22 +99,20 @@ __device__ __forceinline__ void window64(const uint32_t* blk, uint32_t o, uint32
     hi = __builtin_amdgcn_alignbit(w2, w1, r);
 }
 
-/* ---- hard-decision bit planes from En (CDecoder_FAID.cpp:299, :6416-6419; 2B1C :6132-6136) ------------- */
-template <bool WITH_H2>
-__device__ void build_planes(CCode c, const int8_t* sEn, uint32_t* sHard, uint32_t* sHard2, int thr, int tid)
+/* ---- bit plane from En: hard decision En > 0 (CDecoder_FAID.cpp:299, :6416-6419), or with CONF the 2B1C
+ * confidence bit |En| >= thr (CDecoder_FAID_2B1C.cpp:6132-6136) ----------------------------------------- */
+template <bool CONF>
+__device__ void build_plane(CCode c, const int8_t* sEn, uint32_t* plane, int thr, int tid)
 {
     const int N = c->n_var;
     for (int base = 0; base < N; base += LF_T) {
         const int v = base + tid;
         const int e = sEn[v];
-        const unsigned long long h = __ballot(e > 0);
-        unsigned long long h2 = 0;
-        if (WITH_H2) h2 = __ballot(e >= thr || e <= -thr);
+        const unsigned long long h = CONF ? __ballot(e >= thr || e <= -thr) : __ballot(e > 0);
         if ((tid & 63) == 0) {
             const int w = v >> 5;
-            sHard[w] = (uint32_t)h;
-            sHard[w + 1] = (uint32_t)(h >> 32);
-            if (WITH_H2) { sHard2[w] = (uint32_t)h2; sHard2[w + 1] = (uint32_t)(h2 >> 32); }
+            plane[w] = (uint32_t)h;
+            plane[w + 1] = (uint32_t)(h >> 32);
         }
     }
     __syncthreads();
@@ -171,6 +178,120 @@ __device__ __forceinline__ int oms_offset(int x, bool window, bool F, int f1, in
  *   .x bit j (j < 16), .y bit j-16: raw sign s_j of the V2C on edge j, low half row A, high half row B
  *   .z per half: argmin edge | c1 << 5 | c2 << 8 | F << 15, F = XOR_all(s) ^ (deg odd)
  *   Lmn(edge j) = (j == argmin ? c1 : c2), negative iff s_j ^ F */
+/* One layer for the row pair of this thread.  DEG > 0: compile-time degree (no per-edge branches, so the
+ * scheduler can issue all table loads and LDS reads of the row up front and interleave the edges);
+ * DEG == 0: run-time degree `deg` with a guard per edge. */
+template <int METHOD, bool UNIW, int DEG>
+__device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int tid, int br, int deg, int itx, bool window,
+                                            bool lme, int f1, int f2, uint4 cur, bool prA, bool prB, uint32_t vff)
+{
+    constexpr int NJ = DEG > 0 ? DEG : LF_MAX_DEG;
+    uint32_t llo = f->lut_lo[itx][0], lhi = f->lut_hi[itx][0];
+    uint32_t elo = f->lut_ef_lo[itx][0], ehi = f->lut_ef_hi[itx][0];
+    const uint32_t Fo = U(S(cur.z) >> (s2)(15)); /* 0 / 0xffff per half */
+    const uint32_t XL = cur.x ^ Fo, XH = cur.y ^ Fo;
+    const uint32_t IDXo = cur.z & 0x001f001fu;
+    const u2 C1o = US((cur.z >> 5) & 0x00070007u), C2o = US((cur.z >> 8) & 0x00070007u);
+    const u2 DCo = C2o - C1o;
+    uint32_t efmask = 0; /* mask_eef per row, CDecoder_FAID.cpp:713-720 */
+    if (METHOD == 5 && window && lme) efmask = (prA ? 0x0000ffffu : 0u) | (prB ? 0xffff0000u : 0u);
+
+    uint32_t y[NJ];
+    uint32_t sx = 0;
+    u2 k1 = US(0x1fff1fffu), k2 = US(0x1fff1fffu);
+
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (DEG > 0 || j < deg) {
+            /* LDS byte address of row A's variable node: (tid + shift) mod 256 inside the block column */
+            const uint32_t sb = c->circ[br][j].sb;
+            const uint32_t ad = (((uint32_t)tid + sb) & vff) | (sb & ~255u);
+            const int eA = sEn[ad], eB = sEn[ad ^ 128u];
+            const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
+            const u2 ne = pk_minu(US(IDXo ^ JJ(j)), (u2)(1));
+            const u2 mag = pk_mad(ne, DCo, C1o);
+            const s2 sm = S(U(US(j < 16 ? XL : XH) << (u2)(15 - (j & 15)))) >> (s2)(15);
+            const s2 Lmn = S(U(mag) ^ U(sm)) - sm;
+            s2 t = pk_max(E - Lmn, (s2)(SAT_NEG_VAR)); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
+            s2 yy;
+            if (METHOD == 1) {
+                yy = t * (s2)(64) + (s2)(32); /* sign(yy) = (t < 0), CDecoder_OMS.cpp:372 */
+            } else {
+                t = pk_min(t, (s2)(SAT_POS_VAR)); /* CDecoder_FAID.cpp:672 */
+                yy = t * (s2)(64) + E;            /* sign(yy) = sign of (t != 0 ? t : En): back-track, :682 */
+            }
+            y[j] = U(yy);
+            sx ^= U(yy);
+            const s2 a = pk_min(pk_max(t, (s2)(0) - t), (s2)(SAT_POS_MSG)); /* |t| >= 8 maps through column 7 */
+            uint32_t m;
+            if (METHOD == 1) {
+                m = U(a); /* CDecoder_OMS.cpp:374 */
+            } else {
+                if (!UNIW) {
+                    const uint32_t wc = c->circ[br][j].wclass;
+                    llo = f->lut_lo[itx][wc]; lhi = f->lut_hi[itx][wc];
+                    if (METHOD == 5) { elo = f->lut_ef_lo[itx][wc]; ehi = f->lut_ef_hi[itx][wc]; }
+                }
+                const uint32_t sel = U(a) | 0x0c000c00u;
+                m = __builtin_amdgcn_perm(lhi, llo, sel);
+                if (METHOD == 5) {
+                    const uint32_t me = __builtin_amdgcn_perm(ehi, elo, sel);
+                    m = (m & ~efmask) | (me & efmask);
+                }
+            }
+            const u2 key = US((m << 8) | JJ(j));
+            k2 = pk_minu(k2, pk_maxu(k1, key)); /* VECTOR_MIN_2 with the old min1 */
+            k1 = pk_minu(k1, key);
+        }
+    }
+
+    const u2 min1 = k1 >> (u2)(8), min2 = k2 >> (u2)(8);
+    const uint32_t JM = U(k1) & 0x00ff00ffu;
+    u2 C1n, C2n;
+    if (METHOD == 1) {
+        const bool FA = prA && lme, FB = prB && lme;
+        const int a1 = imin(oms_offset(min2.x, window, FA, f1, f2), SAT_POS_MSG); /* cste_1, CDecoder_OMS.cpp:431 */
+        const int a2 = imin(oms_offset(min1.x, window, FA, f1, f2), SAT_POS_MSG); /* cste_2 */
+        const int b1 = imin(oms_offset(min2.y, window, FB, f1, f2), SAT_POS_MSG);
+        const int b2 = imin(oms_offset(min1.y, window, FB, f1, f2), SAT_POS_MSG);
+        C1n = US((uint32_t)(a1 & 0xffff) | ((uint32_t)b1 << 16));
+        C2n = US((uint32_t)(a2 & 0xffff) | ((uint32_t)b2 << 16));
+    } else {
+        C1n = pk_minu(min2, (u2)(SAT_POS_MSG)); /* CDecoder_FAID.cpp:865-866, offset 0 */
+        C2n = pk_minu(min1, (u2)(SAT_POS_MSG));
+    }
+    const u2 DCn = C2n - C1n;
+    /* sign of the new message on edge j: XOR of all signs ^ (deg odd) ^ own sign
+     * (the 0xC0 / 0x40 constants of CDecoder_FAID.cpp:902-906 fed to _mm256_sign_epi8) */
+    const uint32_t Fn = U(S(sx) >> (s2)(15)) ^ (((DEG > 0 ? DEG : deg) & 1) ? 0xffffffffu : 0u);
+
+    uint32_t nXL = 0, nXH = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (DEG > 0 || j < deg) {
+            const s2 yy = S(y[j]);
+            const s2 t = (METHOD == 1) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
+            const u2 ne = pk_minu(US(JM ^ JJ(j)), (u2)(1));
+            const u2 mag = pk_mad(ne, DCn, C1n);
+            const uint32_t sm = U(yy >> (s2)(15)) ^ Fn;
+            const s2 Lmn = S(U(mag) ^ sm) - S(sm);
+            const s2 en = pk_min(pk_max(t + Lmn, (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
+            const uint32_t sb = U(US(U(yy)) >> (u2)(15));
+            if (j < 16) nXL |= sb << j; else nXH |= sb << (j - 16);
+            const uint32_t sb2 = c->circ[br][j].sb;
+            const uint32_t ad = (((uint32_t)tid + sb2) & vff) | (sb2 & ~255u);
+            sEn[ad] = (int8_t)en.x;
+            sEn[ad ^ 128u] = (int8_t)en.y;
+        }
+    }
+    return make_uint4(nXL, nXH, JM | (U(C1n) << 5) | (U(C2n) << 8) | (Fn & 0x80008000u), 0u);
+}
+
+/* ---- one layered iteration (FAID / 2B1C: CDecoder_FAID.cpp:631-1527; OMS: CDecoder_OMS.cpp:334-743) -----
+ * rows: this codeword's compressed messages, [nbr][128] uint4 for the row pair (tid, tid+128); 16-bit halves:
+ *   .x bit j (j < 16), .y bit j-16: raw sign s_j of the V2C on edge j, low half row A, high half row B
+ *   .z per half: argmin edge | c1 << 5 | c2 << 8 | F << 15, F = XOR_all(s) ^ (deg odd)
+ *   Lmn(edge j) = (j == argmin ? c1 : c2), negative iff s_j ^ F */
 template <int METHOD, bool UNIW>
 __device__ void main_step(CCode c, CCfg f, int8_t* sEn, uint4* __restrict__ rows, int tid, int it, uint32_t pA,
                           uint32_t pB, bool lme)
@@ -181,8 +302,8 @@ __device__ void main_step(CCode c, CCfg f, int8_t* sEn, uint4* __restrict__ rows
     const bool window = rem <= f->floor_iter_thresh;
     const int f1 = f->factor_1, f2 = f->factor_2;
     const int nbr = c->nbr;
-    uint32_t llo = f->lut_lo[itx][0], lhi = f->lut_hi[itx][0];
-    uint32_t elo = f->lut_ef_lo[itx][0], ehi = f->lut_ef_hi[itx][0];
+    uint32_t vff;
+    asm volatile("v_mov_b32 %0, 0xff" : "=v"(vff)); /* bit-field-insert mask kept in a VGPR (constant bus) */
 
     uint4 cur = make_uint4(0u, 0u, 0u, 0u); /* Lmn = 0 before the first iteration (CDecoder_FAID.cpp:211-214) */
     if (!fresh) cur = rows[tid];
@@ -190,103 +311,12 @@ __device__ void main_step(CCode c, CCfg f, int8_t* sEn, uint4* __restrict__ rows
         uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
         if (!fresh && br + 1 < nbr) nxt = rows[(br + 1) * LF_T + tid]; /* one layer ahead of use */
         const int deg = c->deg[br];
-        const uint32_t Fo = U(S(cur.z) >> (s2)(15)); /* 0 / 0xffff per half */
-        const uint32_t XL = cur.x ^ Fo, XH = cur.y ^ Fo;
-        const uint32_t IDXo = cur.z & 0x001f001fu;
-        const u2 C1o = US((cur.z >> 5) & 0x00070007u), C2o = US((cur.z >> 8) & 0x00070007u);
-        const u2 DCo = C2o - C1o;
         const bool prA = (pA >> br) & 1u, prB = (pB >> br) & 1u;
-        uint32_t efmask = 0; /* mask_eef per row, CDecoder_FAID.cpp:713-720 */
-        if (METHOD == 5 && window && lme) efmask = (prA ? 0x0000ffffu : 0u) | (prB ? 0xffff0000u : 0u);
-
-        uint32_t y[LF_MAX_DEG];
-        uint32_t sx = 0;
-        u2 k1 = US(0x1fff1fffu), k2 = US(0x1fff1fffu);
-
-#pragma unroll
-        for (int j = 0; j < LF_MAX_DEG; ++j) {
-            if (j < deg) {
-                const uint32_t ci_shift = c->circ[br][j].shift, ci_base = c->circ[br][j].base;
-                const uint32_t adA = (((uint32_t)tid + ci_shift) & 255u) | ci_base;
-                const int eA = sEn[adA], eB = sEn[adA ^ 128u];
-                const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
-                const u2 ne = pk_minu(US(IDXo ^ JJ(j)), (u2)(1));
-                const u2 mag = ne * DCo + C1o;
-                const s2 sm = S(U(US(j < 16 ? XL : XH) << (u2)(15 - (j & 15)))) >> (s2)(15);
-                const s2 Lmn = S(U(mag) ^ U(sm)) - sm;
-                s2 t = pk_max(E - Lmn, (s2)(SAT_NEG_VAR)); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
-                s2 yy;
-                if (METHOD == 1) {
-                    yy = t * (s2)(64) + (s2)(32); /* sign(yy) = (t < 0), CDecoder_OMS.cpp:372 */
-                } else {
-                    t = pk_min(t, (s2)(SAT_POS_VAR)); /* CDecoder_FAID.cpp:672 */
-                    yy = t * (s2)(64) + E;            /* sign(yy) = sign of (t != 0 ? t : En): back-track, :682 */
-                }
-                y[j] = U(yy);
-                sx ^= U(yy);
-                const s2 a = pk_min(pk_max(t, (s2)(0) - t), (s2)(SAT_POS_MSG)); /* |t| >= 8 maps through column 7 */
-                uint32_t m;
-                if (METHOD == 1) {
-                    m = U(a); /* CDecoder_OMS.cpp:374 */
-                } else {
-                    if (!UNIW) {
-                        const uint32_t wc = (ci_shift >> 16) & 3u;
-                        llo = f->lut_lo[itx][wc]; lhi = f->lut_hi[itx][wc];
-                        if (METHOD == 5) { elo = f->lut_ef_lo[itx][wc]; ehi = f->lut_ef_hi[itx][wc]; }
-                    }
-                    const uint32_t sel = U(a) | 0x0c000c00u;
-                    m = __builtin_amdgcn_perm(lhi, llo, sel);
-                    if (METHOD == 5) {
-                        const uint32_t me = __builtin_amdgcn_perm(ehi, elo, sel);
-                        m = (m & ~efmask) | (me & efmask);
-                    }
-                }
-                const u2 key = US((m << 8) | JJ(j));
-                k2 = pk_minu(k2, pk_maxu(k1, key)); /* VECTOR_MIN_2 with the old min1 */
-                k1 = pk_minu(k1, key);
-            }
-        }
-
-        const u2 min1 = k1 >> (u2)(8), min2 = k2 >> (u2)(8);
-        const uint32_t JM = U(k1) & 0x00ff00ffu;
-        u2 C1n, C2n;
-        if (METHOD == 1) {
-            const bool FA = prA && lme, FB = prB && lme;
-            const int a1 = imin(oms_offset(min2.x, window, FA, f1, f2), SAT_POS_MSG); /* cste_1, CDecoder_OMS.cpp:431 */
-            const int a2 = imin(oms_offset(min1.x, window, FA, f1, f2), SAT_POS_MSG); /* cste_2 */
-            const int b1 = imin(oms_offset(min2.y, window, FB, f1, f2), SAT_POS_MSG);
-            const int b2 = imin(oms_offset(min1.y, window, FB, f1, f2), SAT_POS_MSG);
-            C1n = US((uint32_t)(a1 & 0xffff) | ((uint32_t)b1 << 16));
-            C2n = US((uint32_t)(a2 & 0xffff) | ((uint32_t)b2 << 16));
-        } else {
-            C1n = pk_minu(min2, (u2)(SAT_POS_MSG)); /* CDecoder_FAID.cpp:865-866, offset 0 */
-            C2n = pk_minu(min1, (u2)(SAT_POS_MSG));
-        }
-        const u2 DCn = C2n - C1n;
-        /* sign of the new message on edge j: XOR of all signs ^ (deg odd) ^ own sign
-         * (the 0xC0 / 0x40 constants of CDecoder_FAID.cpp:902-906 fed to _mm256_sign_epi8) */
-        const uint32_t Fn = U(S(sx) >> (s2)(15)) ^ ((deg & 1) ? 0xffffffffu : 0u);
-
-        uint32_t nXL = 0, nXH = 0;
-#pragma unroll
-        for (int j = 0; j < LF_MAX_DEG; ++j) {
-            if (j < deg) {
-                const uint32_t ci_shift = c->circ[br][j].shift, ci_base = c->circ[br][j].base;
-                const uint32_t adA = (((uint32_t)tid + ci_shift) & 255u) | ci_base;
-                const s2 yy = S(y[j]);
-                const s2 t = (METHOD == 1) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
-                const u2 ne = pk_minu(US(JM ^ JJ(j)), (u2)(1));
-                const u2 mag = ne * DCn + C1n;
-                const uint32_t sm = U(yy >> (s2)(15)) ^ Fn;
-                const s2 Lmn = S(U(mag) ^ sm) - S(sm);
-                const s2 en = pk_min(pk_max(t + Lmn, (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
-                const uint32_t sb = U(US(U(yy)) >> (u2)(15));
-                if (j < 16) nXL |= sb << j; else nXH |= sb << (j - 16);
-                sEn[adA] = (int8_t)en.x;
-                sEn[adA ^ 128u] = (int8_t)en.y;
-            }
-        }
-        rows[br * LF_T + tid] = make_uint4(nXL, nXH, JM | (U(C1n) << 5) | (U(C2n) << 8) | (Fn & 0x80008000u), 0u);
+        uint4 st;
+        if (deg == 23) st = layer_step<METHOD, UNIW, 23>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff);
+        else if (deg == 22) st = layer_step<METHOD, UNIW, 22>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff);
+        else st = layer_step<METHOD, UNIW, 0>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff);
+        rows[br * LF_T + tid] = st;
         __syncthreads(); /* the next layer reads what this one wrote */
         cur = nxt;
     }
@@ -390,7 +420,7 @@ __device__ void bf_step(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, c
 
 /* ---- the decode kernel: one workgroup per codeword ---------------------------------------------------- */
 template <int METHOD, bool UNIW>
-__global__ __launch_bounds__(LF_T) void lnsfaid_decode_kernel(LfKernelArgs a)
+__global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     CCode c = (CCode)a.code;
@@ -399,9 +429,9 @@ __global__ __launch_bounds__(LF_T) void lnsfaid_decode_kernel(LfKernelArgs a)
     const int cw = (int)blockIdx.x;
     const int N = c->n_var, M = c->n_check, K = c->k_info, nw = c->n_words, pw = c->p_words;
     int8_t* sEn = (int8_t*)smem;
-    uint32_t* sHard0 = (uint32_t*)smem; /* bit-flipping stage: hard_ch overlays the dead En */
+    uint32_t* sHard0 = (uint32_t*)smem;      /* bit-flipping stage: hard_ch and hard2 overlay the dead En */
+    uint32_t* sHard2 = (uint32_t*)smem + nw;
     uint32_t* sHard = (uint32_t*)(smem + lf_lds_off_hard(N));
-    uint32_t* sHard2 = (uint32_t*)(smem + lf_lds_off_hard2(N, nw));
     uint32_t* sP = (uint32_t*)(smem + lf_lds_off_p(N, nw));
     int* sStat = (int*)(smem + lf_lds_off_stat(N, nw, pw));
     int* sRed = sStat + LNSFAID_GROUP;
@@ -474,15 +504,27 @@ __global__ __launch_bounds__(LF_T) void lnsfaid_decode_kernel(LfKernelArgs a)
             if (prog >= t_end) break; /* loops exhausted (also OMS after max_iter iterations) */
             if (max_bf > 0 && prog >= t_bf0 && !in_bf) {
                 /* the layered loop ran out: enter the bit-flipping stage (CDecoder_FAID.cpp:6411-6428) */
-                build_planes<METHOD == 5>(c, sEn, sHard, sHard2, f->hard2_thr, tid);
-                for (int i = tid; i < nw; i += LF_T) sHard0[i] = sHard[i]; /* En is dead from here on */
+                uint32_t conf[LF_MAX_BC * 8 / LF_T]; /* this thread's share of the 2B1C confidence plane */
+                if (METHOD == 5) {
+                    build_plane<true>(c, sEn, sHard, f->hard2_thr, tid); /* staged where the hard plane will go */
+#pragma unroll
+                    for (int k = 0; k < LF_MAX_BC * 8 / LF_T; ++k) conf[k] = (tid + k * LF_T < nw) ? sHard[tid + k * LF_T] : 0u;
+                    __syncthreads();
+                }
+                build_plane<false>(c, sEn, sHard, 0, tid);
+                /* En is dead from here on: its bytes take hard_ch (= hard) and hard2 */
+                for (int i = tid; i < nw; i += LF_T) sHard0[i] = sHard[i];
+                if (METHOD == 5) {
+#pragma unroll
+                    for (int k = 0; k < LF_MAX_BC * 8 / LF_T; ++k) if (tid + k * LF_T < nw) sHard2[tid + k * LF_T] = conf[k];
+                }
                 ls.Th = (int8_t)f->W; ls.l0 = 0; ls.l1 = 0; ls.t = 1;
                 in_bf = true;
                 __syncthreads();
             }
             uint32_t pA, pB;
             if (!in_bf) {
-                build_planes<false>(c, sEn, sHard, sHard2, 0, tid);
+                build_plane<false>(c, sEn, sHard, 0, tid);
                 const int unsat = syndrome(c, a.code, sHard, sP, tid, pA, pB, sRed);
                 if (unsat == 0 && prog >= kmax) break; /* clean on the group's front: park */
                 bool lme;
