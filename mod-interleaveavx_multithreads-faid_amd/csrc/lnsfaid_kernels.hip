@@ -197,6 +197,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     if (METHOD == 5 && window && lme) efmask = (prA ? 0x0000ffffu : 0u) | (prB ? 0xffff0000u : 0u);
 
     uint32_t y[NJ];
+    uint32_t adr[NJ];
     uint32_t sx = 0;
     u2 k1 = US(0x1fff1fffu), k2 = US(0x1fff1fffu);
 
@@ -206,6 +207,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             /* LDS byte address of row A's variable node: (tid + shift) mod 256 inside the block column */
             const uint32_t sb = c->circ[br][j].sb;
             const uint32_t ad = (((uint32_t)tid + sb) & vff) | (sb & ~255u);
+            adr[j] = ad;
             const int eA = sEn[ad], eB = sEn[ad ^ 128u];
             const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
             const u2 ne = pk_minu(US(IDXo ^ JJ(j)), (u2)(1));
@@ -278,8 +280,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             const s2 en = pk_min(pk_max(t + Lmn, (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
             const uint32_t sb = U(US(U(yy)) >> (u2)(15));
             if (j < 16) nXL |= sb << j; else nXH |= sb << (j - 16);
-            const uint32_t sb2 = c->circ[br][j].sb;
-            const uint32_t ad = (((uint32_t)tid + sb2) & vff) | (sb2 & ~255u);
+            const uint32_t ad = adr[j];
             sEn[ad] = (int8_t)en.x;
             sEn[ad ^ 128u] = (int8_t)en.y;
         }

@@ -199,3 +199,71 @@ def test_host_driver_sweep_point_matches_oracle(abi, code50, tmp_path):
         want = [w + x for w, x in zip(want, c)]
     assert got == want, (got, want, res.stdout)
     assert (tmp_path / "Result.txt").exists() and (tmp_path / "Temp.txt").exists()
+
+
+def _derived_code(abi, lib, drop_cols, from_block_row):
+    """A second quasi-cyclic code for the generic code paths: the 50G-PON table with the circulants of the
+    block columns `drop_cols` removed from block rows >= from_block_row (degree 23 -> 23 - len(drop_cols))."""
+    import ctypes as C
+    base = abi.Code50GPON(lib)
+    pos = np.ctypeslib.as_array(base.pos_vn)
+    out, e = [], 0
+    degs = []
+    for r in range(3072):
+        d = 22 if 256 <= r < 512 else 23
+        row = pos[e:e + d]
+        e += d
+        if r // 256 >= from_block_row:
+            row = row[~np.isin(row // 256, drop_cols)]
+        out.append(row)
+        degs.append(len(row))
+    classes, rows = [], []
+    for d in degs:
+        if classes and classes[-1] == d:
+            rows[-1] += 1
+        else:
+            classes.append(d)
+            rows.append(1)
+    flat = np.concatenate(out).astype(np.uint16)
+
+    class Derived:
+        pass
+    dc = Derived()
+    dc.pos_vn = (C.c_uint16 * flat.size)(*flat.tolist())
+    dc.deg = (C.c_int32 * len(classes))(*classes)
+    dc.deg_rows = (C.c_int32 * len(rows))(*rows)
+    dc.code = abi.Code()
+    dc.code.n_var, dc.code.n_check, dc.code.n_edges, dc.code.z = 17664, 3072, int(flat.size), 256
+    dc.code.puncture_tail, dc.code.nb_degres = 384, len(classes)
+    dc.code.deg, dc.code.deg_rows, dc.code.pos_vn = dc.deg, dc.deg_rows, dc.pos_vn
+    dc.N, dc.M, dc.K = 17664, 3072, 17664 - 3072
+    return dc
+
+
+@pytest.mark.parametrize("method", [2, 1, 5])
+def test_other_code_with_runtime_row_degree(abi, lib, method):
+    """Row degrees 23 / 22 / 21: the degree-21 layers take the kernel's run-time-degree path."""
+    dc = _derived_code(abi, lib, [67, 68], 2)
+    assert list(dc.deg) == [23, 22, 21]
+    cfg = abi.default_cfg(method, 10)
+    fix = oa.synth_llr(3, dc.N, 3.9, seed=21 + method)  # a weaker code: decode a little above the waterfall
+    ref, rst = oa.decode_mt(dc, cfg, fix, 3)
+    d = abi.Decoder(dc, cfg, 0, 3)
+    out, st = d.decode(fix, 3)
+    d.close()
+    assert np.array_equal(out, ref) and np.array_equal(st, rst)
+
+
+@pytest.mark.parametrize("method,alpha,W,L0,delta", [(2, 2, 3, 50, 1), (2, 1, 6, 3, 1), (5, 0, 3, 2, 2), (5, 3, 3, 100, 1)])
+def test_bit_flipping_parameter_variants(abi, code50, method, alpha, W, L0, delta):
+    """Non-shipped DTBF / 2B1C constants: alpha outside {0, 1} or a column weight other than 3 take the
+    per-variable-node flip path; alpha = 0 stays on the bit-sliced one."""
+    cfg = abi.default_cfg(method, 4)  # few layered iterations so that the bit-flipping stage has work to do
+    cfg.bf_alpha, cfg.regular_col_weight, cfg.bf_L0, cfg.bf_delta = alpha, W, L0, delta
+    fix = oa.ReferenceChannel(code50, 113, 13.0).groups(3.7, 2)
+    ref, rst = oa.Oracle(code50, cfg).decode(fix, 2)
+    d = abi.Decoder(code50, cfg, 0, 2)
+    out, st = d.decode(fix, 2)
+    d.close()
+    assert rst[:, 1].max() > 0
+    assert np.array_equal(out, ref) and np.array_equal(st, rst)
