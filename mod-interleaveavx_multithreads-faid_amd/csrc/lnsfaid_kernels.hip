@@ -317,7 +317,7 @@ __device__ void main_step(CCode c, CCfg f, int8_t* sEn, uint4* __restrict__ rows
         if (deg == 23) st = layer_step<METHOD, UNIW, 23>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff);
         else if (deg == 22) st = layer_step<METHOD, UNIW, 22>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff);
         else st = layer_step<METHOD, UNIW, 0>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff);
-        rows[br * LF_T + tid] = st;
+        if (rem > 0) rows[br * LF_T + tid] = st; /* the last layered iteration's messages are never read again */
         __syncthreads(); /* the next layer reads what this one wrote */
         cur = nxt;
     }
@@ -583,33 +583,52 @@ __global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
     }
 }
 
-/* ---- CalculateErrors (CLDPC.cpp:4842-4876): one workgroup per frame ----------------------------------- */
+/* ---- CalculateErrors (CLDPC.cpp:4842-4876): one workgroup per group of 32 frames, one frame per wave pass;
+ * 16 B per lane loads when K and N allow; four global atomics per workgroup ----------------------------- */
 __device__ __forceinline__ int nonzero_bytes(uint32_t x)
 {
     return __popc((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(256) void lnsfaid_count_errors_kernel(const int8_t* __restrict__ decoded,
                                                                    const int8_t* __restrict__ input_bits, int n_var,
                                                                    int k_info, unsigned long long* __restrict__ out)
 {
-    __shared__ int sRed[4];
-    const int tid = (int)threadIdx.x;
-    const size_t cw = blockIdx.x;
-    const uint32_t* d = (const uint32_t*)(decoded + cw * (size_t)n_var);
-    const uint32_t* r = input_bits ? (const uint32_t*)(input_bits + cw * (size_t)k_info) : nullptr;
-    int cnt = 0;
-    for (int j = tid; j < (k_info >> 2); j += 256) cnt += nonzero_bytes(d[j] ^ (r ? r[j] : 0u));
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-    if ((tid & 63) == 0) sRed[tid >> 6] = cnt;
+    __shared__ unsigned int sAcc[3];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 3) sAcc[tid] = 0u;
+    __syncthreads();
+    unsigned int frames_err = 0, bits_err = 0, lt3 = 0;
+    for (int fr = wave; fr < LNSFAID_GROUP; fr += 4) {
+        const size_t cw = (size_t)blockIdx.x * LNSFAID_GROUP + (size_t)fr;
+        const int8_t* d = decoded + cw * (size_t)n_var;
+        const int8_t* r = input_bits ? input_bits + cw * (size_t)k_info : nullptr;
+        int cnt = 0;
+        if (WIDE) {
+            const uint4* d4 = (const uint4*)d;
+            const uint4* r4 = (const uint4*)r;
+            for (int j = lane; j < (k_info >> 4); j += 64) {
+                uint4 x = d4[j];
+                if (r) { const uint4 y = r4[j]; x.x ^= y.x; x.y ^= y.y; x.z ^= y.z; x.w ^= y.w; }
+                cnt += nonzero_bytes(x.x) + nonzero_bytes(x.y) + nonzero_bytes(x.z) + nonzero_bytes(x.w);
+            }
+        } else {
+            const uint32_t* d1 = (const uint32_t*)d;
+            const uint32_t* r1 = (const uint32_t*)r;
+            for (int j = lane; j < (k_info >> 2); j += 64) cnt += nonzero_bytes(d1[j] ^ (r ? r1[j] : 0u));
+        }
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+        if (lane == 0 && cnt > 0) { frames_err += 1; bits_err += (unsigned)cnt; lt3 += (cnt < 3) ? 1u : 0u; }
+    }
+    if (lane == 0) { atomicAdd(&sAcc[0], frames_err); atomicAdd(&sAcc[1], bits_err); atomicAdd(&sAcc[2], lt3); }
     __syncthreads();
     if (tid == 0) {
-        const int errorBits = sRed[0] + sRed[1] + sRed[2] + sRed[3];
-        atomicAdd(&out[0], 1ull);
-        if (errorBits > 0) {
-            atomicAdd(&out[1], 1ull);
-            atomicAdd(&out[2], (unsigned long long)errorBits);
-            if (errorBits < 3) atomicAdd(&out[3], 1ull);
+        atomicAdd(&out[0], (unsigned long long)LNSFAID_GROUP);
+        if (sAcc[0]) {
+            atomicAdd(&out[1], (unsigned long long)sAcc[0]);
+            atomicAdd(&out[2], (unsigned long long)sAcc[1]);
+            if (sAcc[2]) atomicAdd(&out[3], (unsigned long long)sAcc[2]);
         }
     }
 }
@@ -638,7 +657,10 @@ extern "C" hipError_t lf_launch_decode(int method, int uniform_w, const LfKernel
 extern "C" hipError_t lf_launch_count_errors(const int8_t* decoded, const int8_t* input_bits, int n_var, int k_info,
                                              size_t n_cw, unsigned long long* out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(lnsfaid_count_errors_kernel, dim3((unsigned)n_cw), dim3(256), 0, stream, decoded, input_bits,
-                       n_var, k_info, out);
+    const dim3 grid((unsigned)(n_cw / LNSFAID_GROUP)), block(256);
+    const bool wide = (k_info % 16 == 0) && (n_var % 16 == 0) && ((uintptr_t)decoded % 16 == 0)
+        && ((uintptr_t)input_bits % 16 == 0);
+    if (wide) hipLaunchKernelGGL(lnsfaid_count_errors_kernel<true>, grid, block, 0, stream, decoded, input_bits, n_var, k_info, out);
+    else hipLaunchKernelGGL(lnsfaid_count_errors_kernel<false>, grid, block, 0, stream, decoded, input_bits, n_var, k_info, out);
     return hipGetLastError();
 }
