@@ -108,7 +108,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=device)
 
