@@ -66,6 +66,26 @@ __device__ __forceinline__ u2 pk_mad(u2 a, u2 b, u2 c)
     return US(r);
 }
 
+/* signed variant, and the two constant forms used for sign multipliers: q = 2*b - 1 and q = 1 - 2*b (b in {0,1}) */
+__device__ __forceinline__ s2 pk_mad_i(s2 a, s2 b, s2 c)
+{
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(U(a)), "v"(U(b)), "v"(U(c)));
+    return S(r);
+}
+__device__ __forceinline__ s2 pk_2b_minus_1(uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, 2, -1 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(b));
+    return S(r);
+}
+__device__ __forceinline__ s2 pk_1_minus_2b(uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, -2, 1 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(b));
+    return S(r);
+}
+
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
@@ -193,6 +213,8 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     const uint32_t IDXo = cur.z & 0x001f001fu;
     const u2 C1o = US((cur.z >> 5) & 0x00070007u), C2o = US((cur.z >> 8) & 0x00070007u);
     const u2 DCo = C2o - C1o;
+    uint32_t c64;
+    asm volatile("v_mov_b32 %0, 0x400040" : "=v"(c64)); /* packed 64 kept in a VGPR for v_pk_mad_i16 */
     uint32_t efmask = 0; /* mask_eef per row, CDecoder_FAID.cpp:713-720 */
     if (METHOD == 5 && window && lme) efmask = (prA ? 0x0000ffffu : 0u) | (prB ? 0xffff0000u : 0u);
 
@@ -212,15 +234,15 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
             const u2 ne = pk_minu(US(IDXo ^ JJ(j)), (u2)(1));
             const u2 mag = pk_mad(ne, DCo, C1o);
-            const s2 sm = S(U(US(j < 16 ? XL : XH) << (u2)(15 - (j & 15)))) >> (s2)(15);
-            const s2 Lmn = S(U(mag) ^ U(sm)) - sm;
-            s2 t = pk_max(E - Lmn, (s2)(SAT_NEG_VAR)); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
+            /* Lmn = neg ? -mag : mag, so En - Lmn = En + q * mag with q = 2 * neg - 1 */
+            const uint32_t nb = ((j < 16 ? XL : XH) >> (j & 15)) & 0x00010001u;
+            s2 t = pk_max(pk_mad_i(pk_2b_minus_1(nb), S(U(mag)), E), (s2)(SAT_NEG_VAR)); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
             s2 yy;
             if (METHOD == 1) {
-                yy = t * (s2)(64) + (s2)(32); /* sign(yy) = (t < 0), CDecoder_OMS.cpp:372 */
+                yy = pk_mad_i(t, S(c64), S(0x00200020u)); /* 64 t + 32: sign(yy) = (t < 0), CDecoder_OMS.cpp:372 */
             } else {
                 t = pk_min(t, (s2)(SAT_POS_VAR)); /* CDecoder_FAID.cpp:672 */
-                yy = t * (s2)(64) + E;            /* sign(yy) = sign of (t != 0 ? t : En): back-track, :682 */
+                yy = pk_mad_i(t, S(c64), E);      /* 64 t + En: sign = sign of (t != 0 ? t : En), back-track :682 */
             }
             y[j] = U(yy);
             sx ^= U(yy);
@@ -266,6 +288,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     /* sign of the new message on edge j: XOR of all signs ^ (deg odd) ^ own sign
      * (the 0xC0 / 0x40 constants of CDecoder_FAID.cpp:902-906 fed to _mm256_sign_epi8) */
     const uint32_t Fn = U(S(sx) >> (s2)(15)) ^ (((DEG > 0 ? DEG : deg) & 1) ? 0xffffffffu : 0u);
+    const uint32_t Fn01 = Fn & 0x00010001u;
 
     uint32_t nXL = 0, nXH = 0;
 #pragma unroll
@@ -275,10 +298,9 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             const s2 t = (METHOD == 1) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
             const u2 ne = pk_minu(US(JM ^ JJ(j)), (u2)(1));
             const u2 mag = pk_mad(ne, DCn, C1n);
-            const uint32_t sm = U(yy >> (s2)(15)) ^ Fn;
-            const s2 Lmn = S(U(mag) ^ sm) - S(sm);
-            const s2 en = pk_min(pk_max(t + Lmn, (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
-            const uint32_t sb = U(US(U(yy)) >> (u2)(15));
+            const uint32_t sb = U(US(U(yy)) >> (u2)(15)); /* raw sign s_j per half */
+            /* new Lmn = (s_j ^ F) ? -mag : mag, so t + Lmn = t + q * mag with q = 1 - 2 * (s_j ^ F) */
+            const s2 en = pk_min(pk_max(pk_mad_i(pk_1_minus_2b(sb ^ Fn01), S(U(mag)), t), (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
             if (j < 16) nXL |= sb << j; else nXH |= sb << (j - 16);
             const uint32_t ad = adr[j];
             sEn[ad] = (int8_t)en.x;
