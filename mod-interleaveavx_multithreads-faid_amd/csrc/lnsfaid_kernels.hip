@@ -66,6 +66,13 @@ __device__ __forceinline__ u2 pk_mad(u2 a, u2 b, u2 c)
     return US(r);
 }
 
+/* 1 where the 16-bit half is non-zero, else 0 (the compiler expands min(x, 1) into compares and selects) */
+__device__ __forceinline__ u2 pk_nonzero(uint32_t x)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(x));
+    return US(r);
+}
 /* signed variant, and the two constant forms used for sign multipliers: q = 2*b - 1 and q = 1 - 2*b (b in {0,1}) */
 __device__ __forceinline__ s2 pk_mad_i(s2 a, s2 b, s2 c)
 {
@@ -232,7 +239,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             adr[j] = ad;
             const int eA = sEn[ad], eB = sEn[ad ^ 128u];
             const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
-            const u2 ne = pk_minu(US(IDXo ^ JJ(j)), (u2)(1));
+            const u2 ne = pk_nonzero(IDXo ^ JJ(j));
             const u2 mag = pk_mad(ne, DCo, C1o);
             /* Lmn = neg ? -mag : mag, so En - Lmn = En + q * mag with q = 2 * neg - 1 */
             const uint32_t nb = ((j < 16 ? XL : XH) >> (j & 15)) & 0x00010001u;
@@ -296,7 +303,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
         if (DEG > 0 || j < deg) {
             const s2 yy = S(y[j]);
             const s2 t = (METHOD == 1) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
-            const u2 ne = pk_minu(US(JM ^ JJ(j)), (u2)(1));
+            const u2 ne = pk_nonzero(JM ^ JJ(j));
             const u2 mag = pk_mad(ne, DCn, C1n);
             const uint32_t sb = U(US(U(yy)) >> (u2)(15)); /* raw sign s_j per half */
             /* new Lmn = (s_j ^ F) ? -mag : mag, so t + Lmn = t + q * mag with q = 1 - 2 * (s_j ^ F) */
