@@ -184,6 +184,28 @@ __device__ int syndrome(CCode c, const LfDevCode* gc, const uint32_t* plane, uin
     return block_sum2(cnt, tid, sRed); /* its barriers also publish sP */
 }
 
+/* ---- cheap "certainly dirty" test for decoders that only need unsat != 0 (DecodeMethod 2: no EF tables, no
+ * selective offset): parity of this thread's two rows of layer 0 straight from En.  The hard decision En > 0
+ * is the sign bit of -En, and the XOR of the sign bits is the sign bit of the XOR.  A non-zero parity anywhere
+ * proves unsat > 0 (the group cannot stop here and the codeword cannot park), so the bit plane and the full
+ * syndrome are only built when layer 0 is clean.  Returns a workgroup-uniform flag. */
+__device__ bool layer0_dirty(CCode c, const int8_t* sEn, int tid, uint32_t vff, int* sRed)
+{
+    const int deg = c->deg[0];
+    int accA = 0, accB = 0;
+#pragma unroll
+    for (int j = 0; j < LF_MAX_DEG; ++j) {
+        if (j < deg) {
+            const uint32_t sb = c->circ[0][j].sb;
+            const uint32_t ad = (((uint32_t)tid + sb) & vff) | (sb & ~255u);
+            accA ^= -(int)sEn[ad];
+            accB ^= -(int)sEn[ad ^ 128u];
+        }
+    }
+    const unsigned long long d = __ballot((accA | accB) < 0);
+    return block_sum2(d != 0ull ? 1 : 0, tid, sRed) != 0;
+}
+
 /* selective offset of OMS_MODE 1 on one minimum (CDecoder_OMS.cpp:388-425); all operands are int8 in the
  * reference and small enough that its saturating adds never saturate */
 __device__ __forceinline__ int oms_offset(int x, bool window, bool F, int f1, int f2)
@@ -526,6 +548,8 @@ __global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
         __syncthreads();
     }
 
+    uint32_t vff0;
+    asm volatile("v_mov_b32 %0, 0xff" : "=v"(vff0));
     /* ---- all 32 lanes parked clean at the same decision point: the group stops here ---- */
     const bool group_stop = (my_status != 0) && all_same;
 
@@ -552,14 +576,17 @@ __global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
                 in_bf = true;
                 __syncthreads();
             }
-            uint32_t pA, pB;
+            uint32_t pA = 0, pB = 0;
             if (!in_bf) {
-                build_plane<false>(c, sEn, sHard, 0, tid);
-                const int unsat = syndrome(c, a.code, sHard, sP, tid, pA, pB, sRed);
-                if (unsat == 0 && prog >= kmax) break; /* clean on the group's front: park */
-                bool lme;
-                if (METHOD == 1) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
-                else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
+                bool lme = false;
+                /* DecodeMethod 2 consumes neither l_checksum_ nor the unsatisfied count, only unsat != 0 */
+                if (METHOD != 2 || !layer0_dirty(c, sEn, tid, vff0, sRed)) {
+                    build_plane<false>(c, sEn, sHard, 0, tid);
+                    const int unsat = syndrome(c, a.code, sHard, sP, tid, pA, pB, sRed);
+                    if (unsat == 0 && prog >= kmax) break; /* clean on the group's front: park */
+                    if (METHOD == 1) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
+                    else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
+                }
                 main_step<METHOD, UNIW>(c, f, sEn, g_rows, tid, prog, pA, pB, lme);
                 prog++;
             } else {
