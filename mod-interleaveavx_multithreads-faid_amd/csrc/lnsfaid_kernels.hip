@@ -157,20 +157,17 @@ __device__ int syndrome(CCode c, const LfDevCode* gc, const uint32_t* plane, uin
     const int nbr = c->nbr;
     uint32_t a = 0, b = 0;
     int cnt = 0;
+    /* lanes 0..31 fetch the windows of rows [64w, 64w+64), lanes 32..63 those of rows [128+64w, ...) */
+    const uint32_t half_off = 64u * (uint32_t)w + ((lane & 32) ? 128u : 0u);
     uint32_t nxt = gc->syn[0][lane & 31]; /* lane-indexed: vector load, one layer ahead */
     for (int br = 0; br < nbr; ++br) {
         const uint32_t e = nxt;
         if (br + 1 < nbr) nxt = gc->syn[br + 1][lane & 31];
-        uint32_t loA = 0, hiA = 0, loB = 0, hiB = 0;
-        if (lane < 32 && e != 0xffffffffu) {
-            const uint32_t* blk = plane + (e >> 8) * 8u;
-            const uint32_t o = ((e & 0xffu) + 64u * (uint32_t)w) & 255u;
-            window64(blk, o, loA, hiA);
-            window64(blk, o ^ 128u, loB, hiB);
-        }
-        loA = xor_reduce32(loA); hiA = xor_reduce32(hiA); loB = xor_reduce32(loB); hiB = xor_reduce32(hiB);
-        const uint32_t rloA = __builtin_amdgcn_readlane(loA, 31), rhiA = __builtin_amdgcn_readlane(hiA, 31);
-        const uint32_t rloB = __builtin_amdgcn_readlane(loB, 31), rhiB = __builtin_amdgcn_readlane(hiB, 31);
+        uint32_t lo = 0, hi = 0;
+        if (e != 0xffffffffu) window64(plane + (e >> 8) * 8u, ((e & 0xffu) + half_off) & 255u, lo, hi);
+        lo = xor_reduce32(lo); hi = xor_reduce32(hi); /* lane 31: rows A, lane 63: rows B */
+        const uint32_t rloA = __builtin_amdgcn_readlane(lo, 31), rhiA = __builtin_amdgcn_readlane(hi, 31);
+        const uint32_t rloB = __builtin_amdgcn_readlane(lo, 63), rhiB = __builtin_amdgcn_readlane(hi, 63);
         if (lane == 0) {
             uint32_t* p = sP + br * 8 + 2 * w;
             p[0] = rloA; p[1] = rhiA; p[4] = rloB; p[5] = rhiB;
