@@ -576,8 +576,11 @@ __global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
             uint32_t pA = 0, pB = 0;
             if (!in_bf) {
                 bool lme = false;
-                /* DecodeMethod 2 consumes neither l_checksum_ nor the unsatisfied count, only unsat != 0 */
-                if (METHOD != 2 || !layer0_dirty(c, sEn, tid, vff0, sRed)) {
+                /* l_checksum_ and the unsatisfied count are consumed only inside the error-floor window
+                 * (nombre_iterations <= floor_iter_thresh: OMS selective offset CDecoder_OMS.cpp:388, 2B1C tables
+                 * CDecoder_FAID.cpp:714) and never by DecodeMethod 2; elsewhere only unsat != 0 matters */
+                const bool needs_checksums = (METHOD != 2) && (max_iter - prog <= f->floor_iter_thresh);
+                if (needs_checksums || !layer0_dirty(c, sEn, tid, vff0, sRed)) {
                     build_plane<false>(c, sEn, sHard, 0, tid);
                     const int unsat = syndrome(c, a.code, sHard, sP, tid, pA, pB, sRed);
                     if (unsat == 0 && prog >= kmax) break; /* clean on the group's front: park */
