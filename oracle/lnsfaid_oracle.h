@@ -21,6 +21,13 @@ int lnsfaid_oracle_decode(lnsfaid_oracle* o, const int8_t* fixInput, size_t n_gr
 int lnsfaid_oracle_count_errors(const lnsfaid_code* code, const int8_t* decodedBits, const int8_t* inputBits,
                                 size_t n_groups, uint64_t out[4]);
 
+/* ---- vectorised CPU port (lnsfaid_cpu_avx2.c): bench.py's cpu_baseline; validated against the oracle ---- */
+typedef struct lnsfaid_cpu lnsfaid_cpu;
+int lnsfaid_cpu_create(lnsfaid_cpu** out, const lnsfaid_code* code, const lnsfaid_cfg* cfg);
+void lnsfaid_cpu_destroy(lnsfaid_cpu* o);
+int lnsfaid_cpu_decode(lnsfaid_cpu* o, const int8_t* fixInput, size_t n_groups, int8_t* decodedBits,
+                       lnsfaid_group_stats* stats);
+
 /* ---- front-end restatement (frontend_oracle.c): the reference's channel for one worker thread --- */
 typedef struct lnsfaid_frontend {
     unsigned long IX, IY, IZ; /* Wichmann-Hill state, RandSeed (CChannel.h:15-20) */

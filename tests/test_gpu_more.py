@@ -114,6 +114,10 @@ def test_baseline_size_batch_properties(abi, code50):
     sample = out2.reshape(ng, 32, N)[early].reshape(-1, N)
     synd = np.add.reduceat(sample[:, pos].astype(np.int64), starts, axis=1) & 1
     assert not synd.any()
+    # (5) every one of the 65 536 frames against the vectorised CPU port (itself pinned to the oracle by
+    # tests/test_oracle.py::test_avx2_port_equals_oracle)
+    ref_all, ref_all_st = oa.decode_mt(code50, cfg, fix2, ng, kind="avx2")
+    assert np.array_equal(out2, ref_all) and np.array_equal(st2, ref_all_st)
     # sample parity with the oracle at this size
     pick = [0, 777, 2047]
     sub = np.concatenate([fix2.reshape(ng, -1)[g] for g in pick])

@@ -90,3 +90,29 @@ def test_count_errors_rule(abi, code50):
     dec[1, 31, [0, K - 1]] = 1
     cnt = oa.Oracle(code50, abi.default_cfg(2, 10)).count_errors(dec.reshape(-1), None, 2)
     assert cnt == [64, 3, 6, 2]
+
+
+@pytest.mark.parametrize("method,max_iter,eb_n0", [(2, 10, 3.5), (2, 10, 4.2), (1, 10, 3.6), (5, 10, 3.55), (2, 6, 3.6), (5, 3, 3.0)])
+def test_avx2_port_equals_oracle(abi, code50, method, max_iter, eb_n0):
+    """The vectorised CPU port used as bench.py's cpu_baseline must agree bit for bit with the pinned oracle."""
+    cfg = abi.default_cfg(method, max_iter)
+    fix = oa.ReferenceChannel(code50, 127, 13.0).groups(eb_n0, 6)
+    ref, rst = oa.decode_mt(code50, cfg, fix, 6)
+    out, st = oa.Oracle(code50, cfg, "avx2").decode(fix, 6)
+    assert np.array_equal(out, ref) and np.array_equal(st, rst)
+
+
+def test_avx2_port_with_nondefault_constants(abi, code50):
+    cfg = abi.default_cfg(1, 10)
+    cfg.factor_1, cfg.factor_2 = 2, 5
+    fix = oa.ReferenceChannel(code50, 131, 13.0).groups(3.5, 3)
+    ref, rst = oa.decode_mt(code50, cfg, fix, 3)
+    out, st = oa.Oracle(code50, cfg, "avx2").decode(fix, 3)
+    assert np.array_equal(out, ref) and np.array_equal(st, rst)
+    cfg = abi.default_cfg(5, 5)
+    cfg.bf_alpha, cfg.bf_L0, cfg.bf_delta = 2, 2, 2
+    for w in range(4):
+        cfg.v2c_map[3][w][2] = 2 + (w == 1)  # class-dependent table row
+    ref, rst = oa.decode_mt(code50, cfg, fix, 3)
+    out, st = oa.Oracle(code50, cfg, "avx2").decode(fix, 3)
+    assert np.array_equal(out, ref) and np.array_equal(st, rst)
