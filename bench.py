@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--max-bf", type=int, default=None, help="override _maxBFiter (experiments only)")
     ap.add_argument("--no-points", action="store_true", help="skip the 3.6 / 4.2 dB side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-groups", type=int, default=1024)
+    ap.add_argument("--cpu-groups", type=int, default=2048)
     args = ap.parse_args()
 
     import numpy as np
