@@ -38,8 +38,12 @@ def algorithmic_bytes(i_layered, j_bf):
     return 2 * N_VAR + i_layered * (4 * N_EDGES + N_VAR) + j_bf * 2 * N_VAR
 
 
-def synth_llr(torch, device, n_groups, eb_n0, seed):
-    sigma = 1.0 / math.sqrt(RATE * 2 * 10.0 ** (0.1 * eb_n0))  # CSimulate.cpp:73
+def synth_llr(torch, device, n_groups, eb_n0, seed, mod_type=2, scale=13.0):
+    """All-zero codeword through the reference's mapper / AWGN / max-log demapper / 4-bit quantiser, on the GPU.
+    mod_type 2: QPSK (LLR = -0.707107 + n); mod_type 4: 16-QAM (per symbol r, i, |r| - c, |i| - c with r, i = -0.316228 + n,
+    reference CModulate.cpp:5, :283-293).  The all-zero word makes every position statistically alike, so the LLRs are drawn
+    directly in the decoder's [32][K] | [32][M] layout."""
+    sigma = 1.0 / math.sqrt(RATE * mod_type * 10.0 ** (0.1 * eb_n0))  # CSimulate.cpp:73
     sigma_ch = sigma / math.sqrt(2.0)  # CSimulate.cpp:126
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -47,9 +51,13 @@ def synth_llr(torch, device, n_groups, eb_n0, seed):
     chunk = 128
     for g0 in range(0, n_groups, chunk):
         g1 = min(n_groups, g0 + chunk)
-        x = torch.randn((g1 - g0, 32 * N_VAR), generator=gen, device=device, dtype=torch.float32)
-        x = x * sigma_ch - 0.707107
-        out[g0:g1] = (x * 13.0).trunc().clamp_(-7, 7).to(torch.int8)  # float2LimitChar_4bit, CLDPC.cpp:4553-4573
+        if mod_type == 2:
+            x = torch.randn((g1 - g0, 32 * N_VAR), generator=gen, device=device, dtype=torch.float32)
+            x = x * sigma_ch - 0.707107
+        else:
+            ri = torch.randn((g1 - g0, 32 * N_VAR // 4, 2), generator=gen, device=device, dtype=torch.float32) * sigma_ch - 0.316228
+            x = torch.cat([ri, ri.abs() - 0.6324555], dim=2).reshape(g1 - g0, 32 * N_VAR)
+        out[g0:g1] = (x * scale).trunc().clamp_(-7, 7).to(torch.int8)  # float2LimitChar_4bit, CLDPC.cpp:4553-4573
     return out
 
 
@@ -71,6 +79,8 @@ def main():
     ap.add_argument("--method", type=int, default=2)
     ap.add_argument("--max-iter", type=int, default=10)
     ap.add_argument("--max-bf", type=int, default=None, help="override _maxBFiter (experiments only)")
+    ap.add_argument("--mod-type", type=int, default=2, choices=[2, 4], help="Profile.txt modType: 2 QPSK, 4 16-QAM")
+    ap.add_argument("--scale", type=float, default=13.0, help="Profile.txt scale (12.5 for the hybrid 2B1C decoder)")
     ap.add_argument("--no-points", action="store_true", help="skip the 3.6 / 4.2 dB side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-groups", type=int, default=2048)
@@ -118,7 +128,7 @@ def main():
         torch.cuda.synchronize()
 
     def run_point(eb_n0, steps, warmup):
-        d_fix = synth_llr(torch, device, n_groups, eb_n0, seed=1234 + 7919 * rank)
+        d_fix = synth_llr(torch, device, n_groups, eb_n0, 1234 + 7919 * rank, args.mod_type, args.scale)
         torch.cuda.synchronize()
         totals = None
 
@@ -174,10 +184,11 @@ def main():
         "dtype": "i8",
         "data": "synthetic",
         "config": {
-            "workload": "50G-PON N=17664 K=14592 Z=256, QPSK all-zero codeword + AWGN, DecodeMethod=%d (%s), "
-                        "MaxIteration=%d, scale 13, %d codewords (%d groups of 32) per GPU, Eb/N0 %.1f dB"
-                        % (args.method, {1: "OMS", 2: "3-bit LNS-FAID FAID3 + DTBF", 5: "FAID + 2B1C"}[args.method],
-                           args.max_iter, n_cw, n_groups, args.eb_n0),
+            "workload": "50G-PON N=17664 K=14592 Z=256, %s all-zero codeword + AWGN, DecodeMethod=%d (%s), "
+                        "MaxIteration=%d, scale %g, %d codewords (%d groups of 32) per GPU, Eb/N0 %.1f dB"
+                        % ({2: "QPSK", 4: "16-QAM"}[args.mod_type], args.method,
+                           {1: "OMS", 2: "3-bit LNS-FAID FAID3 + DTBF", 5: "FAID + 2B1C"}[args.method],
+                           args.max_iter, args.scale, n_cw, n_groups, args.eb_n0),
             "eb_n0_db": args.eb_n0,
             "mean_layered_iterations": head["mean_I"],
             "mean_bf_iterations": head["mean_J"],
@@ -203,7 +214,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_points:
         pts = []
-        for eb in (3.6, 4.2):
+        for eb in ((3.6, 4.2) if args.mod_type == 2 else (8.1, 8.6)):
             del head["d_fix"]
             head["d_fix"] = None
             torch.cuda.empty_cache()
@@ -217,7 +228,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu:
         # bounded CPU sample of the same workload: the first cpu_groups groups of a headline batch
-        d_fix = synth_llr(torch, device, n_groups, args.eb_n0, seed=1234)
+        d_fix = synth_llr(torch, device, n_groups, args.eb_n0, 1234, args.mod_type, args.scale)
         torch.cuda.synchronize()  # the decoder runs on its own stream
         dec.decode_device(d_fix.data_ptr(), n_groups, d_out.data_ptr(), d_stats.data_ptr())
         torch.cuda.synchronize()

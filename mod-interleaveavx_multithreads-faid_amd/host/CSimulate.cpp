@@ -32,15 +32,15 @@ void CSimulate::Initial(Parameter_Simulation& p, int first_index, int streams, i
     m_streams = streams;
     ModulationType = p.mod_type;
     InterleaveModType = p.interleavemod_type;
-    if ((ModulationType != 1 && ModulationType != 2) || InterleaveModType != 1) {
-        fprintf(stderr, "host front-end supports modType 1 (BPSK) / 2 (QPSK) with InterleaveModType 1 only\n");
+    if ((ModulationType != 1 && ModulationType != 2 && ModulationType != 4) || InterleaveModType != 1) {
+        fprintf(stderr, "host front-end supports modType 1 (BPSK) / 2 (QPSK) / 4 (16-QAM) with InterleaveModType 1 only\n");
         exit(EXIT_FAILURE);
     }
     ldpc = new CLDPC();
     ldpc->Initial(p.nb_frames, p.Max_Iteration, streams, device);
     ldpc->SetFactors(p.Factor_1, p.Factor_2);
     const unsigned long SourceLen = (unsigned long)ldpc->m_frame * BitsOverChannelLocal;
-    const unsigned long SymbolLen = ModulationType == 1 ? SourceLen : SourceLen / 2; /* reference CModulate.cpp:66-74 */
+    const unsigned long SymbolLen = SourceLen / (unsigned long)ModulationType; /* reference CModulate.cpp:66-78 */
     channel.resize(streams);
     for (int s = 0; s < streams; ++s) {
         channel[s].RandomSeed = SimulationSeed(first_index + s);
@@ -60,6 +60,7 @@ void CSimulate::Configure(float Eb_N0, int _decode_method)
 void CSimulate::Run()
 {
     static const float table_qpsk[2] = { -0.707107f, 0.707107f }; /* reference CModulate.cpp:4 */
+    static const float table_16qam[4] = { -0.316228f, -0.948683f, 0.316228f, 0.948683f }; /* reference CModulate.cpp:5 */
     const int N = ldpc->m_N, K = ldpc->m_K, M = ldpc->m_M;
     ldpc->FakeEncoder(); /* FAKE_ENCODE path (reference CSimulate.cpp:103-104): GenMatrix is not shipped */
     /* interleave (identity for InterleaveModType 1) + modulate once, reference CSimulate.cpp:111-116.
@@ -71,12 +72,20 @@ void CSimulate::Run()
     if (ModulationType == 1) {
         BPSKModSeq.resize(bits);
         for (int m = 0; m < 32; ++m) for (int k = 0; k < N; ++k) BPSKModSeq[(size_t)m * N + k] = 2.0f * tx_bit(m, k) - 1.0f; /* CModulate.cpp:368 */
-    } else {
+    } else if (ModulationType == 2) {
         ModSeq.resize(bits / 2);
         for (size_t i = 0; i < bits / 2; ++i) {
             const size_t b0 = 2 * i, b1 = 2 * i + 1;
             ModSeq[i].real = table_qpsk[tx_bit((int)(b0 / N), (int)(b0 % N))];
             ModSeq[i].imag = table_qpsk[tx_bit((int)(b1 / N), (int)(b1 % N))];
+        }
+    } else { /* 16-QAM: I index = 2*b0 + b2, Q index = 2*b1 + b3 (reference CModulate.cpp:253-259, half_sym 2) */
+        ModSeq.resize(bits / 4);
+        for (size_t i = 0; i < bits / 4; ++i) {
+            int b[4];
+            for (int u = 0; u < 4; ++u) { const size_t pos = 4 * i + u; b[u] = tx_bit((int)(pos / N), (int)(pos % N)); }
+            ModSeq[i].real = table_16qam[2 * b[0] + b[2]];
+            ModSeq[i].imag = table_16qam[2 * b[1] + b[3]];
         }
     }
     std::vector<float> llr((size_t)m_streams * bits);
@@ -90,9 +99,17 @@ void CSimulate::Run()
             if (ModulationType == 1) {
                 ch.BPSKAWGNChannel(BPSKModSeq.data(), sigma);
                 for (size_t i = 0; i < bits; ++i) dst[i] = ch.BPSKSymbol[i];
-            } else {
+            } else if (ModulationType == 2) {
                 ch.AWGNChannel(ModSeq.data(), (float)(sigma / sqrt(2))); /* reference CSimulate.cpp:126 */
                 for (size_t i = 0; i < bits / 2; ++i) { dst[2 * i] = ch.SymbolSeq[i].real; dst[2 * i + 1] = ch.SymbolSeq[i].imag; } /* Demodulation, CModulate.cpp:276-281 */
+            } else {
+                ch.AWGNChannel(ModSeq.data(), (float)(sigma / sqrt(2)));
+                for (size_t i = 0; i < bits / 4; ++i) { /* max-log demapper, reference CModulate.cpp:283-293 */
+                    dst[4 * i] = ch.SymbolSeq[i].real;
+                    dst[4 * i + 1] = ch.SymbolSeq[i].imag;
+                    dst[4 * i + 2] = fabs(ch.SymbolSeq[i].real) - 0.6324555;
+                    dst[4 * i + 3] = fabs(ch.SymbolSeq[i].imag) - 0.6324555;
+                }
             }
             /* AfterDeModulationDeInterleaver (CModulate.cpp:152-212) + float2LimitChar_4bit, frame-major -> [32][K] | [32][M] */
             for (int m = 0; m < 32; ++m) {

@@ -1,6 +1,6 @@
 /*
  * frontend_oracle.c — CPU restatement of the reference's signal chain in front of the decoder,
- * for ONE worker thread, QPSK, InterleaveModType 1.  TEST INFRASTRUCTURE ONLY (same rule as
+ * for ONE worker thread, QPSK or 16-QAM, InterleaveModType 1.  TEST INFRASTRUCTURE ONLY (same rule as
  * lnsfaid_oracle.c).  It exists so that the oracle can be driven with exactly the LLR stream the
  * reference's own run saw (seed table CSimulate.cpp:11-17), which is what lets the counters recorded
  * in SURVEY.md §6 pin the oracle.
@@ -8,9 +8,9 @@
  * Restated stages, in the order of CSimulate::Run (CSimulate.cpp:103-132):
  *   FakeEncoder            CLDPC.cpp:163-207   every one of the 32 frames carries the same codeword
  *   BeforeModulationInterleaver, InterleaveModType 1   CModulate.cpp:95-148   -> identity per frame
- *   Modulation, QPSK       CModulate.cpp:216-264, table_qpsk CModulate.cpp:4
+ *   Modulation             CModulate.cpp:216-264, table_qpsk / table_16qam CModulate.cpp:4-5
  *   AWGNChannel            CChannel.cpp:71-97   Wichmann-Hill triple + Box-Muller
- *   Demodulation, QPSK     CModulate.cpp:273-281   LLR = (real, imag)
+ *   Demodulation           CModulate.cpp:273-293   QPSK: LLR = (real, imag); 16-QAM adds |real| - c, |imag| - c
  *   AfterDeModulationDeInterleaver   CModulate.cpp:152-212   -> [32][K] then [32][M]
  *   float2LimitChar_4bit   CLDPC.cpp:4524-4582
  */
@@ -86,4 +86,33 @@ void lnsfaid_frontend_qpsk_group(lnsfaid_frontend* fe, int n_var, int n_check, c
             if (k < K) fixInput[(size_t)m * K + k] = q;
             else fixInput[(size_t)32 * K + (size_t)m * n_check + (k - K)] = q;
         }
+}
+
+/* Same for 16-QAM (modType 4): symbol i carries bits 4i..4i+3, I index = 2*b0 + b2, Q index = 2*b1 + b3
+ * (CModulate.cpp:253-259 with half_sym = 2), max-log demapper of CModulate.cpp:283-293. */
+void lnsfaid_frontend_qam16_group(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* codeword, float sigma,
+                                  float scale, int8_t* fixInput)
+{
+    static const float table_16qam[4] = { -0.316228f, -0.948683f, 0.316228f, 0.948683f }; /* CModulate.cpp:5 */
+    const int K = n_var - n_check;
+    const float sigma_ch = (float)(sigma / sqrt(2));
+    const long total = 32L * n_var; /* frame m, bit k at m * n_var + k */
+    for (long i = 0; i < total / 4; ++i) {
+        int b[4];
+        for (int u = 0; u < 4; ++u) b[u] = codeword ? codeword[(4 * i + u) % n_var] : 0;
+        const float re = random_norm(sigma_ch, fe) + table_16qam[2 * b[0] + b[2]];
+        const float im = random_norm(sigma_ch, fe) + table_16qam[2 * b[1] + b[3]];
+        float llr[4];
+        llr[0] = re;
+        llr[1] = im;
+        llr[2] = fabs(re) - 0.6324555; /* double arithmetic, stored as float (CModulate.cpp:290-291) */
+        llr[3] = fabs(im) - 0.6324555;
+        for (int u = 0; u < 4; ++u) {
+            const long pos = 4 * i + u;
+            const int m = (int)(pos / n_var), k = (int)(pos % n_var);
+            const int8_t q = quantise_4bit(llr[u], scale);
+            if (k < K) fixInput[(size_t)m * K + k] = q;
+            else fixInput[(size_t)32 * K + (size_t)m * n_check + (k - K)] = q;
+        }
+    }
 }

@@ -44,6 +44,10 @@ float lnsfaid_frontend_sigma(float eb_n0_db, int mod_type, double rate);
 void lnsfaid_frontend_qpsk_group(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* codeword, float sigma,
                                  float scale, int8_t* fixInput);
 
+/* the same loop body for 16-QAM, modType 4 (table_16qam CModulate.cpp:5, demapper CModulate.cpp:283-293) */
+void lnsfaid_frontend_qam16_group(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* codeword, float sigma,
+                                  float scale, int8_t* fixInput);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,7 @@ _SYMS = {
     "lnsfaid_frontend_seed": (None, [C.POINTER(Frontend), C.c_int]),
     "lnsfaid_frontend_sigma": (C.c_float, [C.c_float, C.c_int, C.c_double]),
     "lnsfaid_frontend_qpsk_group": (None, [C.POINTER(Frontend), C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
+    "lnsfaid_frontend_qam16_group": (None, [C.POINTER(Frontend), C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
 }
 
 _lib = None
@@ -103,23 +104,25 @@ class ReferenceChannel:
 
     RATE = 0.8444444  # m_Rate, reference CLDPC.cpp:4780
 
-    def __init__(self, code50, seed=101, scale=13.0):
+    def __init__(self, code50, seed=101, scale=13.0, mod_type=2):
         self.lib = load()
         self.code50 = code50
         self.fe = Frontend()
         self.scale = scale
+        self.mod_type = mod_type  # 2 QPSK, 4 16-QAM (Profile.txt modType)
         self.lib.lnsfaid_frontend_seed(C.byref(self.fe), seed)
 
     def groups(self, eb_n0_db, n_groups, codeword=None):
         N, M = self.code50.N, self.code50.M
-        sigma = self.lib.lnsfaid_frontend_sigma(eb_n0_db, 2, self.RATE)
+        sigma = self.lib.lnsfaid_frontend_sigma(eb_n0_db, self.mod_type, self.RATE)
+        gen = {2: self.lib.lnsfaid_frontend_qpsk_group, 4: self.lib.lnsfaid_frontend_qam16_group}[self.mod_type]
         out = np.empty((n_groups, 32 * N), dtype=np.int8)
         cw = None
         if codeword is not None:
             codeword = np.ascontiguousarray(codeword, dtype=np.int8)
             cw = codeword.ctypes.data
         for g in range(n_groups):
-            self.lib.lnsfaid_frontend_qpsk_group(C.byref(self.fe), N, M, cw, sigma, self.scale, out[g].ctypes.data)
+            gen(C.byref(self.fe), N, M, cw, sigma, self.scale, out[g].ctypes.data)
         return out.reshape(-1)
 
 

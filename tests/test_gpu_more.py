@@ -179,26 +179,29 @@ def test_oms_factors_and_nondefault_tables(abi, code50):
     d.close()
 
 
-def test_host_driver_sweep_point_matches_oracle(abi, code50, tmp_path):
+@pytest.mark.parametrize("mod_type,method,scale,eb_n0", [(2, 2, 13.0, 3.5), (4, 5, 12.5, 8.1)], ids=["qpsk_faid", "16qam_2b1c"])
+def test_host_driver_sweep_point_matches_oracle(abi, code50, tmp_path, mod_type, method, scale, eb_n0):
     """The CLDPC/CSimulate-shaped C++ driver (host/lnsfaid_sim): 4 streams (reference threads 0..3, seeds
-    101, 103, 107, 109), one round of 50 calls at 3.5 dB, DecodeMethod 2; counters against the oracle fed by
-    the restated channel with the same seeds."""
+    101, 103, 107, 109), one round of 50 calls at one Eb/N0 point; counters against the oracle fed by the restated
+    channel with the same seeds.  Covers Profile.txt parsing, the DecodeMethod switch and the host front-end."""
     exe = os.path.join(oa.PKG_DIR, "host", "lnsfaid_sim")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(oa.PKG_DIR, "host")])
     prof = open(os.path.join(oa.PKG_DIR, "host", "Profile.txt")).read()
-    prof = prof.replace("StartSNR: 3.3", "StartSNR: 3.5").replace("EndSNR: 3.85", "EndSNR: 3.55")
+    prof = prof.replace("StartSNR: 3.3", "StartSNR: %g" % eb_n0).replace("EndSNR: 3.85", "EndSNR: %g" % (eb_n0 + 0.05))
+    prof = prof.replace("DecodeMethod: 2", "DecodeMethod: %d" % method).replace("modType: 2", "modType: %d" % mod_type)
+    prof = prof.replace("scale: 13", "scale: %g" % scale)
     (tmp_path / "Profile.txt").write_text(prof)
     res = subprocess.run([exe, "--streams", "4", "--gpus", "1", "--max-rounds", "1"], cwd=tmp_path, capture_output=True,
                          text=True, timeout=600)
     assert res.returncode == 0, res.stderr
-    row = [l for l in res.stdout.splitlines() if re.match(r"\s*3\.5\s", l)][-1].split()
+    row = [l for l in res.stdout.splitlines() if re.match(r"\s*%g\s" % eb_n0, l)][-1].split()
     got = [int(row[1]), int(row[2]), int(row[3]), int(row[6])]
-    cfg = abi.default_cfg(2, 10)
+    cfg = abi.default_cfg(method, 10)
     want = [0, 0, 0, 0]
     for s, seed in enumerate([101, 103, 107, 109]):
-        fix = oa.ReferenceChannel(code50, seed, 13.0).groups(3.5, 50)
-        dec, _ = oa.decode_mt(code50, cfg, fix, 50)
+        fix = oa.ReferenceChannel(code50, seed, scale, mod_type=mod_type).groups(eb_n0, 50)
+        dec, _ = oa.decode_mt(code50, cfg, fix, 50, kind="avx2")
         c = oa.Oracle(code50, cfg).count_errors(dec, None, 50)
         want = [w + x for w, x in zip(want, c)]
     assert got == want, (got, want, res.stdout)
@@ -270,4 +273,17 @@ def test_bit_flipping_parameter_variants(abi, code50, method, alpha, W, L0, delt
     out, st = d.decode(fix, 2)
     d.close()
     assert rst[:, 1].max() > 0
+    assert np.array_equal(out, ref) and np.array_equal(st, rst)
+
+
+@pytest.mark.parametrize("eb_n0", [8.1, 8.6])
+def test_hybrid_2b1c_on_16qam(abi, code50, eb_n0):
+    """BASELINE.json configs[4]: DecodeMethod 5 (hybrid-precision FAID + 2B1C), 16-QAM, scale 12.5 (reference
+    README.md:20), LLRs from the restated reference mapper / max-log demapper."""
+    cfg = abi.default_cfg(5, 10)
+    fix = oa.ReferenceChannel(code50, 101, 12.5, mod_type=4).groups(eb_n0, 6)
+    ref, rst = oa.decode_mt(code50, cfg, fix, 6)
+    d = abi.Decoder(code50, cfg, 0, 6)
+    out, st = d.decode(fix, 6)
+    d.close()
     assert np.array_equal(out, ref) and np.array_equal(st, rst)
