@@ -69,7 +69,7 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
     memset(out, 0, sizeof(*out));
     if (!code || !code->pos_vn || !code->deg || !code->deg_rows) return LNSFAID_E_INVAL;
     const int Z = code->z, N = code->n_var, M = code->n_check, E = code->n_edges;
-    if (Z != LF_Z) return LNSFAID_E_CODE; /* kernels map one circulant row to one of 256 threads */
+    if (Z != LF_Z) return LNSFAID_E_CODE; /* kernels map the 256 rows of a circulant onto 128 threads x 2 rows */
     if (N <= 0 || M <= 0 || N % Z || M % Z || M >= N) return LNSFAID_E_CODE;
     const int nbr = M / Z, nbc = N / Z, K = N - M;
     if (nbr > LF_MAX_BR || nbc > LF_MAX_BC) return LNSFAID_E_CODE;
