@@ -154,6 +154,32 @@ int lnsfaid_count_errors(lnsfaid_ctx* ctx, const int8_t* decodedBits, const int8
 int lnsfaid_count_errors_device(lnsfaid_ctx* ctx, const int8_t* d_decodedBits,
                                 const int8_t* d_inputBits, size_t n_groups, uint64_t out[4]);
 
+/* ---- front-end on the device (optional, the host generator stays the parity source) ---- */
+
+/*
+ * Generates the fixInput of n_streams groups on the GPU, one group per reference worker thread ("stream"):
+ * replaces, for one pass of the loop body of CSimulate::Run (CSimulate.cpp:126-132),
+ *   CChannel::AWGNChannel (CChannel.cpp:71-97, Wichmann-Hill + Box-Muller, seed table CSimulate.cpp:11-17),
+ *   CModulate::Demodulation + AfterDeModulationDeInterleaver (CModulate.cpp:152-212, :273-293) and
+ *   CLDPC::float2LimitChar_4bit (CLDPC.cpp:4553-4573).
+ *   seeds[s]        RandomSeed of stream s (IX = IY = IZ = seed, CChannel.cpp:121)
+ *   draws_before[s] uniforms stream s has consumed so far; one group consumes lnsfaid_frontend_draws_per_group()
+ *   mod_type        Profile.txt modType: 2 (QPSK) or 4 (16-QAM); InterleaveModType 1
+ *   sigma           CSimulate::Configure's sigma (CSimulate.cpp:69-74); the channel adds N(0, (sigma/sqrt 2)^2) per axis
+ *   codeword        host, [n_var] bits 0/1 sent in every frame (FakeEncoder), NULL = all-zero
+ *   d_fixInput      device, n_streams groups in the decoder's layout
+ * Integer and float stages are bit-exact; Box-Muller uses the device's double log / cos, so single LLRs can
+ * differ from the host generator's (rate bounded in tests/test_gpu_frontend.py).
+ */
+int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, const uint64_t* draws_before, size_t n_streams,
+                            int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput);
+uint64_t lnsfaid_frontend_draws_per_group(const lnsfaid_ctx* ctx, int32_t mod_type);
+
+/* The context's own device staging buffers (each max_groups * 32 * n_var bytes): the fixInput buffer the
+ * host-pointer entry points copy into and the decodedBits buffer they copy out of.  A host driver without its own
+ * device allocator (host/CLDPC.cpp) runs front-end -> decode -> counters on them with the *_device entry points. */
+int lnsfaid_io_buffers(lnsfaid_ctx* ctx, int8_t** d_fixInput, int8_t** d_decodedBits, lnsfaid_group_stats** d_stats);
+
 /* ---- measurement hooks ------------------------------------------------------- */
 
 /* Device time (HIP events on the context's stream) and launch count of the

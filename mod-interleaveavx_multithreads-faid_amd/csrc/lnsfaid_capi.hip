@@ -20,6 +20,10 @@ extern "C" hipError_t lf_launch_decode(int method, int uniform_w, const LfKernel
 extern "C" hipError_t lf_launch_count_errors(const int8_t* decoded, const int8_t* input_bits, int n_var, int k_info,
                                              size_t n_cw, unsigned long long* out, hipStream_t stream);
 
+extern "C" hipError_t lf_launch_frontend(const uint32_t* d_seeds, const unsigned long long* d_draws, int n_streams, int mod_type,
+                                         float sigma_ch, float scale, const int8_t* d_codeword, int n_var, int n_check,
+                                         int8_t* d_fix, hipStream_t stream);
+
 static thread_local char g_hip_err[256] = "";
 
 static int hip_fail(hipError_t e, const char* what)
@@ -59,6 +63,10 @@ struct lnsfaid_ctx {
     lnsfaid_group_stats* d_io_stats = nullptr;
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
+    /* device front-end scratch: seeds, draw counters, transmitted codeword */
+    uint32_t* d_fe_seeds = nullptr;
+    unsigned long long* d_fe_draws = nullptr;
+    int8_t* d_fe_codeword = nullptr;
 };
 
 /* ---- code analysis: PosNoeudsVariable -> circulants ------------------------------------------------- */
@@ -180,6 +188,7 @@ extern "C" void lnsfaid_destroy(lnsfaid_ctx* ctx)
     (void)hipFree(ctx->d_bits); (void)hipFree(ctx->d_lane); (void)hipFree(ctx->d_status[0]); (void)hipFree(ctx->d_status[1]);
     (void)hipFree(ctx->d_remaining); (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_io_in); (void)hipFree(ctx->d_io_out); (void)hipFree(ctx->d_io_stats);
+    (void)hipFree(ctx->d_fe_seeds); (void)hipFree(ctx->d_fe_draws); (void)hipFree(ctx->d_fe_codeword);
     if (ctx->h_remaining) (void)hipHostFree(ctx->h_remaining);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -310,6 +319,18 @@ static int ensure_io(lnsfaid_ctx* ctx)
     return LNSFAID_OK;
 }
 
+extern "C" int lnsfaid_io_buffers(lnsfaid_ctx* ctx, int8_t** d_fixInput, int8_t** d_decodedBits, lnsfaid_group_stats** d_stats)
+{
+    if (!ctx) return LNSFAID_E_INVAL;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int rc = ensure_io(ctx);
+    if (rc) return rc;
+    if (d_fixInput) *d_fixInput = ctx->d_io_in;
+    if (d_decodedBits) *d_decodedBits = ctx->d_io_out;
+    if (d_stats) *d_stats = ctx->d_io_stats;
+    return LNSFAID_OK;
+}
+
 extern "C" int lnsfaid_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, size_t n_groups, int8_t* decodedBits,
                               lnsfaid_group_stats* stats)
 {
@@ -365,6 +386,37 @@ extern "C" int lnsfaid_count_errors(lnsfaid_ctx* ctx, const int8_t* decodedBits,
         d_in = ctx->d_io_in;
     }
     return lnsfaid_count_errors_device(ctx, ctx->d_io_out, d_in, n_groups, out);
+}
+
+/* ---- front-end on the device ------------------------------------------------------------------------ */
+extern "C" uint64_t lnsfaid_frontend_draws_per_group(const lnsfaid_ctx* ctx, int32_t mod_type)
+{
+    if (!ctx || (mod_type != 2 && mod_type != 4)) return 0;
+    /* 32 * n_var / mod_type symbols, 2 normals per symbol, 2 uniforms per normal */
+    return (uint64_t)32 * (uint64_t)ctx->n_var / (uint64_t)mod_type * 4u;
+}
+
+extern "C" int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, const uint64_t* draws_before, size_t n_streams,
+                                       int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput)
+{
+    if (!ctx || !seeds || !draws_before || !d_fixInput || (mod_type != 2 && mod_type != 4)) return LNSFAID_E_INVAL;
+    if (n_streams == 0) return LNSFAID_OK;
+    if (n_streams > ctx->max_groups || (32L * ctx->n_var) % (mod_type * 2) != 0) return LNSFAID_E_INVAL;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->d_fe_seeds) {
+        HIP_TRY(hipMalloc(&ctx->d_fe_seeds, ctx->max_groups * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&ctx->d_fe_draws, ctx->max_groups * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&ctx->d_fe_codeword, (size_t)ctx->n_var));
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->d_fe_seeds, seeds, n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_fe_draws, draws_before, n_streams * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (codeword) HIP_TRY(hipMemcpyAsync(ctx->d_fe_codeword, codeword, (size_t)ctx->n_var, hipMemcpyHostToDevice, ctx->stream));
+    /* AWGNChannel(ModSeq, sigma / sqrt(2)): float / double -> double, narrowed to float (CSimulate.cpp:126) */
+    const float sigma_ch = (float)((double)sigma / 1.4142135623730951);
+    HIP_TRY(lf_launch_frontend(ctx->d_fe_seeds, ctx->d_fe_draws, (int)n_streams, mod_type, sigma_ch, scale,
+                               codeword ? ctx->d_fe_codeword : nullptr, ctx->n_var, ctx->n_check, d_fixInput, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); /* seeds / draws_before may be reused by the caller */
+    return LNSFAID_OK;
 }
 
 /* ---- measurement hooks / misc ---------------------------------------------------------------------- */

@@ -1,0 +1,125 @@
+/*
+ * lnsfaid_frontend.hip — the reference's signal chain in front of the decoder, generated on the GPU
+ * (SURVEY.md §8(f) N1).  One launch produces the `fixInput` of n_streams groups: stream s plays the reference's
+ * worker thread with RandomSeed seeds[s] (CSimulate.cpp:11-17, :57) and has already consumed draws_before[s]
+ * uniforms of its Wichmann-Hill generator.
+ *
+ *   CChannel::Random_Uniform  CChannel.cpp:71-80   three multiplicative congruential generators, float sum, fraction
+ *   CChannel::Random_Norm     CChannel.cpp:82-89   Box-Muller in double from two consecutive uniforms
+ *   CChannel::AWGNChannel     CChannel.cpp:90-97   real then imag of each symbol
+ *   CModulate::Modulation / Demodulation, QPSK and 16-QAM   CModulate.cpp:216-293
+ *   AfterDeModulationDeInterleaver (InterleaveModType 1)     CModulate.cpp:152-212
+ *   CLDPC::float2LimitChar_4bit   CLDPC.cpp:4553-4573
+ *
+ * The sequential generator is parallelised exactly: the state after n draws is X0 * a^n mod m, so every thread
+ * jumps to its first draw with a modular power and then steps its own run.  The integer and single-precision parts
+ * are bit-exact; Box-Muller uses the device's double-precision log / cos, which are not guaranteed to round like
+ * glibc's, so a quantised LLR can differ from the host generator's once in many millions (the host generator,
+ * host/CChannel.cpp = oracle/frontend_oracle.c, stays the parity source; tests bound the mismatch rate).
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "lnsfaid.h"
+
+#define FE_RUN 16 /* symbols (QPSK: LLR pairs, 16-QAM: LLR quadruples) per thread */
+
+__device__ __forceinline__ uint32_t modpow(uint32_t a, unsigned long long e, uint32_t m)
+{
+    uint32_t r = 1u, b = a % m;
+    while (e) {
+        if (e & 1ull) r = (r * b) % m; /* operands < 2^16: no overflow */
+        b = (b * b) % m;
+        e >>= 1;
+    }
+    return r;
+}
+
+struct WH { uint32_t ix, iy, iz; };
+
+__device__ __forceinline__ float wh_uniform(WH& s)
+{
+    s.ix = (s.ix * 249u) % 61967u;
+    s.iy = (s.iy * 251u) % 63443u;
+    s.iz = (s.iz * 252u) % 63599u;
+    float temp = (((float)s.ix) / ((float)61967)) + (((float)s.iy) / ((float)63443)) + (((float)s.iz) / ((float)63599));
+    temp -= (float)(int)temp;
+    return temp;
+}
+
+__device__ __forceinline__ float wh_norm(double sigma, WH& s)
+{
+    const float u1 = wh_uniform(s);
+    const float u2 = wh_uniform(s);
+    return (float)(sigma * cos(2 * 3.1415926535897932384626433832795 * (double)u2) * sqrt(-2.0 * log(1.0 - (double)u1)));
+}
+
+__device__ __forceinline__ int8_t quantise_4bit(float x, float scale)
+{
+    const float y = x * scale;
+    int q = (y > -2147483648.0f && y < 2147483648.0f) ? (int)y : (int)0x80000000; /* cvttps2dq */
+    q = q > 127 ? 127 : (q < -128 ? -128 : q);                                      /* saturating packs */
+    return (int8_t)(q > 7 ? 7 : (q < -7 ? -7 : q));
+}
+
+/* position of bit k of frame m inside one group's fixInput: [32][K] then [32][M] */
+__device__ __forceinline__ size_t fix_pos(long pos, int n_var, int k_info, int n_check)
+{
+    const int m = (int)(pos / n_var), k = (int)(pos % n_var);
+    return k < k_info ? (size_t)m * k_info + k : (size_t)32 * k_info + (size_t)m * n_check + (k - k_info);
+}
+
+__global__ __launch_bounds__(256) void lnsfaid_frontend_kernel(const uint32_t* __restrict__ seeds,
+                                                               const unsigned long long* __restrict__ draws_before, int mod_type,
+                                                               float sigma_ch, float scale, const int8_t* __restrict__ codeword,
+                                                               int n_var, int n_check, int8_t* __restrict__ fix_input)
+{
+    const int stream = (int)blockIdx.y;
+    const long bits = 32L * n_var;
+    const long symbols = bits / mod_type;
+    const long first = ((long)blockIdx.x * 256 + threadIdx.x) * FE_RUN;
+    if (first >= symbols) return;
+    const int k_info = n_var - n_check;
+    int8_t* out = fix_input + (size_t)stream * (size_t)bits;
+    /* symbol i uses normals 2i and 2i+1, normal k uses uniforms 2k+1 and 2k+2 of the stream */
+    const unsigned long long skip = draws_before[stream] + 4ull * (unsigned long long)first;
+    const uint32_t seed = seeds[stream];
+    WH s;
+    s.ix = (uint32_t)(((unsigned long long)(seed % 61967u) * modpow(249u, skip, 61967u)) % 61967u);
+    s.iy = (uint32_t)(((unsigned long long)(seed % 63443u) * modpow(251u, skip, 63443u)) % 63443u);
+    s.iz = (uint32_t)(((unsigned long long)(seed % 63599u) * modpow(252u, skip, 63599u)) % 63599u);
+    const double sigma = (double)sigma_ch;
+    const long last = first + FE_RUN < symbols ? first + FE_RUN : symbols;
+    for (long i = first; i < last; ++i) {
+        if (mod_type == 2) {
+            const int b0 = codeword ? codeword[(2 * i) % n_var] : 0, b1 = codeword ? codeword[(2 * i + 1) % n_var] : 0;
+            const float re = wh_norm(sigma, s) + (b0 ? 0.707107f : -0.707107f);
+            const float im = wh_norm(sigma, s) + (b1 ? 0.707107f : -0.707107f);
+            out[fix_pos(2 * i, n_var, k_info, n_check)] = quantise_4bit(re, scale);
+            out[fix_pos(2 * i + 1, n_var, k_info, n_check)] = quantise_4bit(im, scale);
+        } else {
+            int b[4];
+            for (int u = 0; u < 4; ++u) b[u] = codeword ? codeword[(4 * i + u) % n_var] : 0;
+            const float t16[4] = { -0.316228f, -0.948683f, 0.316228f, 0.948683f };
+            const float re = wh_norm(sigma, s) + t16[2 * b[0] + b[2]];
+            const float im = wh_norm(sigma, s) + t16[2 * b[1] + b[3]];
+            const float l2 = (float)(fabs((double)re) - 0.6324555), l3 = (float)(fabs((double)im) - 0.6324555);
+            out[fix_pos(4 * i, n_var, k_info, n_check)] = quantise_4bit(re, scale);
+            out[fix_pos(4 * i + 1, n_var, k_info, n_check)] = quantise_4bit(im, scale);
+            out[fix_pos(4 * i + 2, n_var, k_info, n_check)] = quantise_4bit(l2, scale);
+            out[fix_pos(4 * i + 3, n_var, k_info, n_check)] = quantise_4bit(l3, scale);
+        }
+    }
+}
+
+extern "C" hipError_t lf_launch_frontend(const uint32_t* d_seeds, const unsigned long long* d_draws, int n_streams, int mod_type,
+                                         float sigma_ch, float scale, const int8_t* d_codeword, int n_var, int n_check,
+                                         int8_t* d_fix, hipStream_t stream)
+{
+    const long symbols = 32L * n_var / mod_type;
+    const unsigned bx = (unsigned)((symbols + 256L * FE_RUN - 1) / (256L * FE_RUN));
+    hipLaunchKernelGGL(lnsfaid_frontend_kernel, dim3(bx, (unsigned)n_streams), dim3(256), 0, stream, d_seeds, d_draws, mod_type,
+                       sigma_ch, scale, d_codeword, n_var, n_check, d_fix);
+    return hipGetLastError();
+}

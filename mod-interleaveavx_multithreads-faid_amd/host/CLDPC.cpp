@@ -14,7 +14,7 @@ static void die(const char* what, int rc)
 CLDPC::CLDPC()
     : m_Rate(0), inputBits(nullptr), outputBits(nullptr), decodedBits(nullptr), fixInput(nullptr), nb_iteration(0),
       m_M(0), m_N(0), m_K(0), m_PunLen(0), m_ShortenLen(0), m_frame(0), m_groups(0), m_stats(nullptr), m_device(0),
-      m_factor_1(1), m_factor_2(6)
+      m_factor_1(1), m_factor_2(6), m_device_io(false)
 {
     memset(m_ctx, 0, sizeof(m_ctx));
 }
@@ -71,7 +71,7 @@ void CLDPC::float2LimitChar_4bit(int8_t* output, const float* input, float scale
     }
 }
 
-void CLDPC::decode_with(int method)
+lnsfaid_ctx* CLDPC::context(int method)
 {
     lnsfaid_cfg cfg;
     int rc = lnsfaid_cfg_default(&cfg, method, nb_iteration);
@@ -85,8 +85,40 @@ void CLDPC::decode_with(int method)
         rc = lnsfaid_set_cfg(m_ctx[method], &cfg);
         if (rc) die("lnsfaid_set_cfg", rc);
     }
-    rc = lnsfaid_decode(m_ctx[method], fixInput, (size_t)m_groups, decodedBits, m_stats);
+    return m_ctx[method];
+}
+
+void CLDPC::decode_with(int method)
+{
+    lnsfaid_ctx* ctx = context(method);
+    int rc;
+    if (m_device_io) {
+        int8_t *d_fix = nullptr, *d_out = nullptr;
+        lnsfaid_group_stats* d_st = nullptr;
+        rc = lnsfaid_io_buffers(ctx, &d_fix, &d_out, &d_st);
+        if (rc) die("lnsfaid_io_buffers", rc);
+        rc = lnsfaid_decode_device(ctx, d_fix, (size_t)m_groups, d_out, nullptr);
+    } else {
+        rc = lnsfaid_decode(ctx, fixInput, (size_t)m_groups, decodedBits, m_stats);
+    }
     if (rc) die("lnsfaid_decode", rc);
+}
+
+void CLDPC::DeviceChannel(int decode_method, const uint32_t* seeds, const uint64_t* draws_before, int mod_type, float sigma,
+                          float scale)
+{
+    lnsfaid_ctx* ctx = context(decode_method);
+    int8_t* d_fix = nullptr;
+    int rc = lnsfaid_io_buffers(ctx, &d_fix, nullptr, nullptr);
+    if (rc) die("lnsfaid_io_buffers", rc);
+    rc = lnsfaid_frontend_device(ctx, seeds, draws_before, (size_t)m_groups, mod_type, sigma, scale, nullptr, d_fix);
+    if (rc) die("lnsfaid_frontend_device", rc);
+    m_device_io = true;
+}
+
+uint64_t CLDPC::DrawsPerGroup(int mod_type)
+{
+    return (uint64_t)32 * (uint64_t)m_N / (uint64_t)mod_type * 4u; /* 2 normals per symbol, 2 uniforms per normal */
 }
 
 void CLDPC::Decode_OMS() { decode_with(1); }
@@ -99,7 +131,14 @@ Statistic CLDPC::CalculateErrors()
     for (auto c : m_ctx) if (c) ctx = c;
     if (!ctx) die("CalculateErrors before any Decode_*", LNSFAID_E_INVAL);
     uint64_t out[4] = { 0, 0, 0, 0 };
-    const int rc = lnsfaid_count_errors(ctx, decodedBits, inputBits, (size_t)m_groups, out);
+    int rc;
+    if (m_device_io) {
+        int8_t* d_out = nullptr;
+        rc = lnsfaid_io_buffers(ctx, nullptr, &d_out, nullptr);
+        if (!rc) rc = lnsfaid_count_errors_device(ctx, d_out, nullptr /* all-zero codeword */, (size_t)m_groups, out);
+    } else {
+        rc = lnsfaid_count_errors(ctx, decodedBits, inputBits, (size_t)m_groups, out);
+    }
     if (rc) die("lnsfaid_count_errors", rc);
     Statistic s;
     s.ErrorFrame = out[1]; s.ErrorBits = out[2]; s.LT3ErrBitFrame = out[3];

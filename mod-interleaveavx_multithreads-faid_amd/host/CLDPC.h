@@ -49,6 +49,14 @@ public:
     void Decode_FAID_2B1C(); /* DecodeMethod 5 */
     Statistic CalculateErrors();
 
+    /* Device-resident mode (--device-frontend): the channel output of `m_groups` reference worker threads is
+     * generated on the GPU straight into the decoder's input buffer, Decode_*() and CalculateErrors() then work on
+     * device buffers and fixInput / decodedBits on the host are not touched.  All-zero codeword only (FakeEncoder
+     * with the shipped CodeWord_sym). */
+    void DeviceChannel(int decode_method, const uint32_t* seeds, const uint64_t* draws_before, int mod_type, float sigma,
+                       float scale);
+    uint64_t DrawsPerGroup(int mod_type);
+
     /* Factor_1 / Factor_2 as the reference re-reads them from Profile.txt on every decode call */
     void SetFactors(int factor_1, int factor_2) { m_factor_1 = factor_1; m_factor_2 = factor_2; }
     const lnsfaid_group_stats* GroupStats() const { return m_stats; }
@@ -56,10 +64,12 @@ public:
 
 private:
     void decode_with(int method);
+    lnsfaid_ctx* context(int method);
     lnsfaid_ctx* m_ctx[6]; /* one context per DecodeMethod, created on first use */
     lnsfaid_code m_code;
     int32_t m_deg[NB_DEGRES], m_deg_rows[NB_DEGRES];
     lnsfaid_group_stats* m_stats;
     int m_device, m_factor_1, m_factor_2;
+    bool m_device_io;
 };
 #endif

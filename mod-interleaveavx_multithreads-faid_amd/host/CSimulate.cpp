@@ -42,6 +42,7 @@ void CSimulate::Initial(Parameter_Simulation& p, int first_index, int streams, i
     const unsigned long SourceLen = (unsigned long)ldpc->m_frame * BitsOverChannelLocal;
     const unsigned long SymbolLen = SourceLen / (unsigned long)ModulationType; /* reference CModulate.cpp:66-78 */
     channel.resize(streams);
+    m_draws.assign(streams, 0);
     for (int s = 0; s < streams; ++s) {
         channel[s].RandomSeed = SimulationSeed(first_index + s);
         channel[s].Initial(SymbolLen, first_index + s);
@@ -88,11 +89,30 @@ void CSimulate::Run()
             ModSeq[i].imag = table_16qam[2 * b[1] + b[3]];
         }
     }
-    std::vector<float> llr((size_t)m_streams * bits);
+    std::vector<float> llr(device_frontend ? 0 : (size_t)m_streams * bits);
+    std::vector<uint32_t> seeds(m_streams);
+    for (int s = 0; s < m_streams; ++s) seeds[s] = (uint32_t)channel[s].RandomSeed;
     for (int call = 0; call < 50; ++call) {
         TestFrame += 32ul * m_streams;
+        if (device_frontend) {
+            if (ModulationType == 1) { fprintf(stderr, "--device-frontend needs modType 2 or 4\n"); exit(EXIT_FAILURE); }
+            ldpc->DeviceChannel(decode_method, seeds.data(), m_draws.data(), ModulationType, sigma, scale);
+            const uint64_t n = ldpc->DrawsPerGroup(ModulationType);
+            for (int s = 0; s < m_streams; ++s) {
+                m_draws[s] += n;
+                /* keep RS (the resume table of Temp.txt) where the host generator would be: X <- X * a^n mod m */
+                auto jump = [n](unsigned long x, unsigned long a, unsigned long m) {
+                    unsigned long r = 1, b = a % m; uint64_t e = n;
+                    while (e) { if (e & 1) r = r * b % m; b = b * b % m; e >>= 1; }
+                    return x % m * r % m;
+                };
+                channel[s].RS.IX = jump(channel[s].RS.IX, 249, 61967);
+                channel[s].RS.IY = jump(channel[s].RS.IY, 251, 63443);
+                channel[s].RS.IZ = jump(channel[s].RS.IZ, 252, 63599);
+            }
+        }
 #pragma omp parallel for schedule(dynamic, 1)
-        for (int s = 0; s < m_streams; ++s) {
+        for (int s = 0; s < (device_frontend ? 0 : m_streams); ++s) {
             float* dst = llr.data() + (size_t)s * bits;
             CChannel& ch = channel[s];
             int8_t* fix = ldpc->fixInput + (size_t)s * bits;
@@ -127,7 +147,8 @@ void CSimulate::Run()
             exit(EXIT_FAILURE);
         }
         decode_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        for (int s = 0; s < m_streams; ++s) { sum_iterations += ldpc->GroupStats()[s].iterations; sum_bf_iterations += ldpc->GroupStats()[s].bf_iterations; }
+        if (!device_frontend)
+            for (int s = 0; s < m_streams; ++s) { sum_iterations += ldpc->GroupStats()[s].iterations; sum_bf_iterations += ldpc->GroupStats()[s].bf_iterations; }
         decoded_groups += m_streams;
         const Statistic Test = ldpc->CalculateErrors();
         ErrorFrame += Test.ErrorFrame;

@@ -24,6 +24,7 @@ public:
     float sigma = 0, snr = 0, scale = 0;
     int decode_method = 0, ModulationType = 2, InterleaveModType = 1;
     double decode_seconds = 0; /* host wall time spent inside Decode_*() */
+    bool device_frontend = false; /* generate the channel output on the GPU (lnsfaid_frontend_device) */
     unsigned long sum_iterations = 0, sum_bf_iterations = 0, decoded_groups = 0;
 
     ~CSimulate();
@@ -35,6 +36,7 @@ private:
     std::vector<Complex8> ModSeq;   /* modulated fixed codeword of one group (QPSK) */
     std::vector<float> BPSKModSeq;
     int m_first = 0, m_streams = 0;
+    std::vector<uint64_t> m_draws; /* uniforms consumed per stream (device front-end) */
 };
 
 int SimulationSeed(int index); /* the reference's seed table, CSimulate.cpp:11-17 */

@@ -29,13 +29,15 @@ using namespace std;
 int main(int argc, char** argv)
 {
     int streams = 64, gpus = 1, max_rounds = 0;
+    bool device_frontend = false;
     const char* profile = "Profile.txt";
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--streams") && i + 1 < argc) streams = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--profile") && i + 1 < argc) profile = argv[++i];
         else if (!strcmp(argv[i], "--max-rounds") && i + 1 < argc) max_rounds = atoi(argv[++i]); /* 0 = reference stop rule only */
-        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R]\n", argv[0]); return 2; }
+        else if (!strcmp(argv[i], "--device-frontend")) device_frontend = true; /* channel + demapper + quantiser on the GPU */
+        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R] [--device-frontend]\n", argv[0]); return 2; }
     }
     if (streams < 1 || gpus < 1 || gpus > streams) { fprintf(stderr, "need 1 <= gpus <= streams\n"); return 2; }
 
@@ -49,6 +51,7 @@ int main(int argc, char** argv)
     vector<CSimulate> simulate(gpus);
     for (int g = 0; g < gpus; ++g) {
         const int first = (int)((long)streams * g / gpus), last = (int)((long)streams * (g + 1) / gpus);
+        simulate[g].device_frontend = device_frontend;
         simulate[g].Initial(p_simulation, first, last - first, g);
     }
 

@@ -64,6 +64,10 @@ SYMBOLS = {
     "lnsfaid_decode_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "lnsfaid_count_errors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "lnsfaid_count_errors_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "lnsfaid_frontend_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_size_t, C.c_int32,
+                                          C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "lnsfaid_frontend_draws_per_group": (C.c_uint64, [C.c_void_p, C.c_int32]),
+    "lnsfaid_io_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "lnsfaid_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32]),
     "lnsfaid_stream": (C.c_void_p, [C.c_void_p]),
     "lnsfaid_strerror": (C.c_char_p, [C.c_int]),

@@ -179,8 +179,10 @@ def test_oms_factors_and_nondefault_tables(abi, code50):
     d.close()
 
 
-@pytest.mark.parametrize("mod_type,method,scale,eb_n0", [(2, 2, 13.0, 3.5), (4, 5, 12.5, 8.1)], ids=["qpsk_faid", "16qam_2b1c"])
-def test_host_driver_sweep_point_matches_oracle(abi, code50, tmp_path, mod_type, method, scale, eb_n0):
+@pytest.mark.parametrize("mod_type,method,scale,eb_n0,extra", [(2, 2, 13.0, 3.5, []), (4, 5, 12.5, 8.1, []),
+                                                               (2, 2, 13.0, 3.5, ["--device-frontend"])],
+                         ids=["qpsk_faid", "16qam_2b1c", "qpsk_faid_device_frontend"])
+def test_host_driver_sweep_point_matches_oracle(abi, code50, tmp_path, mod_type, method, scale, eb_n0, extra):
     """The CLDPC/CSimulate-shaped C++ driver (host/lnsfaid_sim): 4 streams (reference threads 0..3, seeds
     101, 103, 107, 109), one round of 50 calls at one Eb/N0 point; counters against the oracle fed by the restated
     channel with the same seeds.  Covers Profile.txt parsing, the DecodeMethod switch and the host front-end."""
@@ -192,7 +194,7 @@ def test_host_driver_sweep_point_matches_oracle(abi, code50, tmp_path, mod_type,
     prof = prof.replace("DecodeMethod: 2", "DecodeMethod: %d" % method).replace("modType: 2", "modType: %d" % mod_type)
     prof = prof.replace("scale: 13", "scale: %g" % scale)
     (tmp_path / "Profile.txt").write_text(prof)
-    res = subprocess.run([exe, "--streams", "4", "--gpus", "1", "--max-rounds", "1"], cwd=tmp_path, capture_output=True,
+    res = subprocess.run([exe, "--streams", "4", "--gpus", "1", "--max-rounds", "1"] + extra, cwd=tmp_path, capture_output=True,
                          text=True, timeout=600)
     assert res.returncode == 0, res.stderr
     row = [l for l in res.stdout.splitlines() if re.match(r"\s*%g\s" % eb_n0, l)][-1].split()
