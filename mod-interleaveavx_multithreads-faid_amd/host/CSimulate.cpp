@@ -111,7 +111,7 @@ void CSimulate::Run()
                 channel[s].RS.IZ = jump(channel[s].RS.IZ, 252, 63599);
             }
         }
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) if (!device_frontend)
         for (int s = 0; s < (device_frontend ? 0 : m_streams); ++s) {
             float* dst = llr.data() + (size_t)s * bits;
             CChannel& ch = channel[s];

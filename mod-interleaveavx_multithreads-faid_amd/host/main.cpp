@@ -28,6 +28,9 @@ using namespace std;
 
 int main(int argc, char** argv)
 {
+    /* OpenMP workers must sleep, not spin, between the channel loops: a spinning pool starves the HIP runtime's
+     * threads while the GPU decodes (set before the OpenMP runtime starts) */
+    setenv("OMP_WAIT_POLICY", "passive", 0);
     int streams = 64, gpus = 1, max_rounds = 0;
     bool device_frontend = false;
     const char* profile = "Profile.txt";
