@@ -289,3 +289,27 @@ def test_hybrid_2b1c_on_16qam(abi, code50, eb_n0):
     out, st = d.decode(fix, 6)
     d.close()
     assert np.array_equal(out, ref) and np.array_equal(st, rst)
+
+
+@pytest.mark.parametrize("method,eb_n0", [(2, 3.5), (2, 3.65), (1, 3.6), (5, 3.55)])
+def test_random_codewords(abi, code50, method, eb_n0):
+    """64 groups of per-frame different random codewords (systematic encoder of tests/gf2_encoder.py; the reference
+    can only send one fixed word because its GenMatrix data is not shipped): decoder parity on signs of both
+    polarities, and the counter pass against the transmitted information bits."""
+    import gf2_encoder as ge
+    enc = ge.Encoder(code50)
+    ng = 64
+    rng = np.random.default_rng(100 + method)
+    info = rng.integers(0, 2, size=(ng * 32, code50.K), dtype=np.uint8)
+    cw = enc.encode(info)
+    fix = ge.qpsk_llr(cw, eb_n0, seed=method)
+    cfg = abi.default_cfg(method, 10)
+    ref, rst = oa.decode_mt(code50, cfg, fix, ng, kind="avx2")
+    inp = np.ascontiguousarray(info.astype(np.int8).reshape(-1))
+    d = abi.Decoder(code50, cfg, 0, ng)
+    out, st = d.decode(fix, ng)
+    cnt = d.count_errors(out, inp, ng)
+    d.close()
+    assert np.array_equal(out, ref) and np.array_equal(st, rst)
+    assert cnt == oa.Oracle(code50, cfg).count_errors(ref, inp, ng)
+    assert cnt[1] < ng * 32  # not everything fails: the words really are codewords

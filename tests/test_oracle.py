@@ -116,3 +116,27 @@ def test_avx2_port_with_nondefault_constants(abi, code50):
     ref, rst = oa.decode_mt(code50, cfg, fix, 3)
     out, st = oa.Oracle(code50, cfg, "avx2").decode(fix, 3)
     assert np.array_equal(out, ref) and np.array_equal(st, rst)
+
+
+def test_random_codewords_oracle_and_avx2_port(abi, code50):
+    """Per-frame different, non-zero codewords (tests/gf2_encoder.py): noiseless words are fixed points, noisy ones
+    decode identically in the oracle and the AVX2 port, and the counters use the transmitted information bits."""
+    import gf2_encoder as ge
+    enc = ge.Encoder(code50)
+    rng = np.random.default_rng(7)
+    info = rng.integers(0, 2, size=(64, code50.K), dtype=np.uint8)
+    cw = enc.encode(info)
+    clean = ge.to_group_layout(np.where(cw > 0, 7, -7).astype(np.int8), code50.K)
+    for method in (1, 2, 5):
+        cfg = abi.default_cfg(method, 10)
+        out, st = oa.Oracle(code50, cfg).decode(clean, 2)
+        assert np.array_equal(out.reshape(64, code50.N), cw) and st.tolist() == [[1, 0], [1, 0]]
+    cfg = abi.default_cfg(2, 10)
+    fix = ge.qpsk_llr(cw, 3.55, seed=3)
+    ref, rst = oa.decode_mt(code50, cfg, fix, 2)
+    out, st = oa.Oracle(code50, cfg, "avx2").decode(fix, 2)
+    assert np.array_equal(out, ref) and np.array_equal(st, rst)
+    inp = np.ascontiguousarray(info.astype(np.int8).reshape(-1))
+    cnt = oa.Oracle(code50, cfg).count_errors(ref, inp, 2)
+    err = (ref.reshape(64, code50.N)[:, :code50.K] != info).sum(axis=1)
+    assert cnt == [64, int((err > 0).sum()), int(err.sum()), int(((err > 0) & (err < 3)).sum())]
