@@ -38,3 +38,9 @@ def lib(abi):
 @pytest.fixture(scope="session")
 def code50(abi, lib):
     return abi.Code50GPON(lib)
+
+
+@pytest.fixture(scope="session")
+def encoder(code50):
+    import gf2_encoder
+    return gf2_encoder.Encoder(code50)

@@ -35,12 +35,15 @@ class Encoder:
             mask[col] = False
             packed[mask] ^= packed[col]
         self.Binv = np.unpackbits(packed, axis=1)[:, M:2 * M]
+        self.At = np.ascontiguousarray(self.A.T.astype(np.float32))
+        self.Binvt = np.ascontiguousarray(self.Binv.T.astype(np.float32))
 
     def encode(self, info):
         """info: [n, K] bits -> codewords [n, N]."""
         info = np.asarray(info, dtype=np.uint8)
-        s = (info.astype(np.int64) @ self.A.T.astype(np.int64)) & 1          # A u
-        p = (s @ self.Binv.T.astype(np.int64)) & 1                           # B^-1 A u
+        # float32 BLAS products are exact here: every dot product is an integer below 2^24
+        s = np.rint(info.astype(np.float32) @ self.At).astype(np.int64) & 1          # A u
+        p = np.rint(s.astype(np.float32) @ self.Binvt).astype(np.int64) & 1          # B^-1 A u
         return np.concatenate([info, p.astype(np.uint8)], axis=1).astype(np.int8)
 
 

@@ -292,12 +292,12 @@ def test_hybrid_2b1c_on_16qam(abi, code50, eb_n0):
 
 
 @pytest.mark.parametrize("method,eb_n0", [(2, 3.5), (2, 3.65), (1, 3.6), (5, 3.55)])
-def test_random_codewords(abi, code50, method, eb_n0):
+def test_random_codewords(abi, code50, encoder, method, eb_n0):
     """64 groups of per-frame different random codewords (systematic encoder of tests/gf2_encoder.py; the reference
     can only send one fixed word because its GenMatrix data is not shipped): decoder parity on signs of both
     polarities, and the counter pass against the transmitted information bits."""
     import gf2_encoder as ge
-    enc = ge.Encoder(code50)
+    enc = encoder
     ng = 64
     rng = np.random.default_rng(100 + method)
     info = rng.integers(0, 2, size=(ng * 32, code50.K), dtype=np.uint8)

@@ -118,11 +118,11 @@ def test_avx2_port_with_nondefault_constants(abi, code50):
     assert np.array_equal(out, ref) and np.array_equal(st, rst)
 
 
-def test_random_codewords_oracle_and_avx2_port(abi, code50):
+def test_random_codewords_oracle_and_avx2_port(abi, code50, encoder):
     """Per-frame different, non-zero codewords (tests/gf2_encoder.py): noiseless words are fixed points, noisy ones
     decode identically in the oracle and the AVX2 port, and the counters use the transmitted information bits."""
     import gf2_encoder as ge
-    enc = ge.Encoder(code50)
+    enc = encoder
     rng = np.random.default_rng(7)
     info = rng.integers(0, 2, size=(64, code50.K), dtype=np.uint8)
     cw = enc.encode(info)
