@@ -139,7 +139,7 @@ static void build_wcols(LfDevCode* code, int W)
 static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
 {
     if (!cfg) return LNSFAID_E_INVAL;
-    if (cfg->decode_method != 1 && cfg->decode_method != 2 && cfg->decode_method != 5) return LNSFAID_E_INVAL;
+    if (cfg->decode_method != 1 && cfg->decode_method != 2 && cfg->decode_method != 4 && cfg->decode_method != 5) return LNSFAID_E_INVAL;
     if (cfg->max_iteration < 0 || cfg->max_iteration > (1 << 20)) return LNSFAID_E_INVAL;
     if (cfg->max_bf_iter < 0 || cfg->max_bf_iter > (1 << 20)) return LNSFAID_E_INVAL;
     if (cfg->regular_col_weight < 0 || cfg->regular_col_weight > LF_MAX_COLW) return LNSFAID_E_INVAL;
@@ -162,7 +162,7 @@ static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
         for (int w = 0; w < 4; ++w) {
             for (int a = 0; a < 8; ++a) {
                 const int v = cfg->v2c_map[it][w][a], ve = cfg->v2c_map_ef[it][w][a];
-                if (cfg->decode_method != 1 && (v < 0 || v > 7)) return LNSFAID_E_INVAL; /* 3-bit message alphabet */
+                if (cfg->decode_method != 1 && cfg->decode_method != 4 && (v < 0 || v > 7)) return LNSFAID_E_INVAL; /* 3-bit message alphabet */
                 if (cfg->decode_method == 5 && (ve < 0 || ve > 7)) return LNSFAID_E_INVAL;
                 uint32_t* l = a < 4 ? &out->lut_lo[it][w] : &out->lut_hi[it][w];
                 uint32_t* le = a < 4 ? &out->lut_ef_lo[it][w] : &out->lut_ef_hi[it][w];

@@ -264,7 +264,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             const uint32_t nb = ((j < 16 ? XL : XH) >> (j & 15)) & 0x00010001u;
             s2 t = pk_max(pk_mad_i(pk_2b_minus_1(nb), S(U(mag)), E), (s2)(SAT_NEG_VAR)); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
             s2 yy;
-            if (METHOD == 1) {
+            if (METHOD == 1 || METHOD == 4) {
                 yy = pk_mad_i(t, S(c64), S(0x00200020u)); /* 64 t + 32: sign(yy) = (t < 0), CDecoder_OMS.cpp:372 */
             } else {
                 t = pk_min(t, (s2)(SAT_POS_VAR)); /* CDecoder_FAID.cpp:672 */
@@ -274,7 +274,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             sx ^= U(yy);
             const s2 a = pk_min(pk_max(t, (s2)(0) - t), (s2)(SAT_POS_MSG)); /* |t| >= 8 maps through column 7 */
             uint32_t m;
-            if (METHOD == 1) {
+            if (METHOD == 1 || METHOD == 4) {
                 m = U(a); /* CDecoder_OMS.cpp:374 */
             } else {
                 if (!UNIW) {
@@ -298,7 +298,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     const u2 min1 = k1 >> (u2)(8), min2 = k2 >> (u2)(8);
     const uint32_t JM = U(k1) & 0x00ff00ffu;
     u2 C1n, C2n;
-    if (METHOD == 1) {
+    if (METHOD == 1 || METHOD == 4) {
         const bool FA = prA && lme, FB = prB && lme;
         const int a1 = imin(oms_offset(min2.x, window, FA, f1, f2), SAT_POS_MSG); /* cste_1, CDecoder_OMS.cpp:431 */
         const int a2 = imin(oms_offset(min1.x, window, FA, f1, f2), SAT_POS_MSG); /* cste_2 */
@@ -321,7 +321,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     for (int j = 0; j < NJ; ++j) {
         if (DEG > 0 || j < deg) {
             const s2 yy = S(y[j]);
-            const s2 t = (METHOD == 1) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
+            const s2 t = (METHOD == 1 || METHOD == 4) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
             const u2 ne = pk_nonzero(JM ^ JJ(j));
             const u2 mag = pk_mad(ne, DCn, C1n);
             const uint32_t sb = U(US(U(yy)) >> (u2)(15)); /* raw sign s_j per half */
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
                     build_plane<false>(c, sEn, sHard, 0, tid);
                     const int unsat = syndrome(c, a.code, sHard, sP, tid, pA, pB, sRed);
                     if (unsat == 0 && prog >= kmax) break; /* clean on the group's front: park */
-                    if (METHOD == 1) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
+                    if (METHOD == 1 || METHOD == 4) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
                     else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
                 }
                 main_step<METHOD, UNIW>(c, f, sEn, g_rows, tid, prog, pA, pB, lme);
@@ -705,6 +705,7 @@ extern "C" hipError_t lf_launch_decode(int method, int uniform_w, const LfKernel
     switch (method) {
     case 1: return launch_method<1>(true, args, lds_bytes, stream); /* OMS has no look-up table */
     case 2: return launch_method<2>(uniform_w != 0, args, lds_bytes, stream);
+    case 4: return launch_method<4>(true, args, lds_bytes, stream); /* OMS arithmetic + DTBF */
     case 5: return launch_method<5>(uniform_w != 0, args, lds_bytes, stream);
     default: return hipErrorInvalidValue;
     }

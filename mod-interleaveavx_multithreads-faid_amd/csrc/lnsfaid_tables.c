@@ -104,6 +104,15 @@ int lnsfaid_cfg_default(lnsfaid_cfg* cfg, int32_t decode_method, int32_t max_ite
         cfg->bf_L0 = 0;
         for (int it = 0; it < 6; ++it) fill_map(cfg->v2c_map[it], ident); /* min(|t|,7), CDecoder_OMS.cpp:374 */
         break;
+    case 4: /* Decode_OMS_DTBF: the OMS layered loop followed by the DTBF stage with its own constants */
+        cfg->floor_err_count = 100;  /* CDecoder_OMS_DTBF.cpp:33 */
+        cfg->floor_iter_thresh = 4;  /* CDecoder_OMS_DTBF.cpp:34 */
+        cfg->ef_elimination = 0;
+        cfg->max_bf_iter = 50;       /* CDecoder_OMS_DTBF.cpp:35 */
+        cfg->bf_L0 = 0;              /* CDecoder_OMS_DTBF.cpp:7  */
+        cfg->bf_L1 = 50;             /* CDecoder_OMS_DTBF.cpp:8  */
+        for (int it = 0; it < 6; ++it) fill_map(cfg->v2c_map[it], ident);
+        break;
     case 2: /* Decode_FAID */
         cfg->floor_err_count = 0;    /* CDecoder_FAID.cpp:193 */
         cfg->floor_iter_thresh = -1; /* CDecoder_FAID.cpp:194 */

@@ -40,7 +40,7 @@ static inline V sel(V mask, V a, V b) { return _mm256_blendv_epi8(b, a, mask); }
 int lnsfaid_cpu_create(lnsfaid_cpu** out, const lnsfaid_code* code, const lnsfaid_cfg* cfg)
 {
     if (!out || !code || !cfg || !code->pos_vn) return LNSFAID_E_INVAL;
-    if (cfg->decode_method != 1 && cfg->decode_method != 2 && cfg->decode_method != 5) return LNSFAID_E_INVAL;
+    if (cfg->decode_method != 1 && cfg->decode_method != 2 && cfg->decode_method != 4 && cfg->decode_method != 5) return LNSFAID_E_INVAL;
     lnsfaid_cpu* o = (lnsfaid_cpu*)calloc(1, sizeof(*o));
     if (!o) return LNSFAID_E_NOMEM;
     o->code = *code;
@@ -114,7 +114,8 @@ static void decode_group(lnsfaid_cpu* o, const int8_t* fix, int8_t* out, lnsfaid
 {
     const lnsfaid_cfg* c = &o->cfg;
     const int N = o->code.n_var, M = o->code.n_check, K = N - M, E = o->code.n_edges;
-    const int oms = c->decode_method == 1, ef = c->ef_elimination >= 1;
+    const int oms = c->decode_method == 1 || c->decode_method == 4, ef = c->ef_elimination >= 1;
+    const int with_bf = c->decode_method != 1;
     const V zero = _mm256_setzero_si256(), one = set1(1), ones = set1(-1);
     const V vmin = set1(-31), vmax = set1(31), v7 = set1(7), sbit = set1((char)0x80);
     const V f1 = set1(c->factor_1), f2 = set1(c->factor_2);
@@ -209,7 +210,7 @@ static void decode_group(lnsfaid_cpu* o, const int8_t* fix, int8_t* out, lnsfaid
     }
 
     int bf = 0;
-    if (!oms) {
+    if (with_bf) {
         const int W = c->regular_col_weight, two_bit = c->decode_method == 5;
         const V thr = set1(c->hard2_threshold), nthr = set1(-c->hard2_threshold);
         for (int i = 0; i < N; ++i) {
@@ -274,7 +275,7 @@ static void decode_group(lnsfaid_cpu* o, const int8_t* fix, int8_t* out, lnsfaid
     {
         int8_t tmp[L];
         for (int v = 0; v < N; ++v) {
-            const V b = oms ? _mm256_and_si256(gt(o->En[v], zero), one) : _mm256_and_si256(o->hard[v], one);
+            const V b = !with_bf ? _mm256_and_si256(gt(o->En[v], zero), one) : _mm256_and_si256(o->hard[v], one);
             _mm256_storeu_si256((V*)tmp, b);
             for (int l = 0; l < L; ++l) out[(size_t)l * N + v] = tmp[l];
         }

@@ -11,6 +11,8 @@
  *   - Decode_OMS        reference CDecoder_OMS.cpp:13-2998      (DecodeMethod 1)
  *   - Decode_FAID       reference CDecoder_FAID.cpp:176-7135    (DecodeMethod 2, FAID + DTBF)
  *   - Decode_FAID_2B1C  reference CDecoder_FAID_2B1C.cpp:96-6866 (DecodeMethod 5)
+ *   - Decode_OMS_DTBF   reference CDecoder_OMS_DTBF.cpp:18-3692  (DecodeMethod 4: its layered loop is textually
+ *                       Decode_OMS's and its bit-flipping stage textually Decode_FAID's, checked by diff)
  *   - CalculateErrors   reference CLDPC.cpp:4842-4876
  * The reference unrolls its row loop once per degree class (DEG_1..DEG_3); the three copies are
  * textually identical up to the degree (checked by diff), so one generic row loop is used here.
@@ -97,7 +99,7 @@ struct lnsfaid_oracle {
 int lnsfaid_oracle_create(lnsfaid_oracle** out, const lnsfaid_code* code, const lnsfaid_cfg* cfg)
 {
     if (!out || !code || !cfg || !code->pos_vn) return LNSFAID_E_INVAL;
-    if (cfg->decode_method != 1 && cfg->decode_method != 2 && cfg->decode_method != 5) return LNSFAID_E_INVAL;
+    if (cfg->decode_method != 1 && cfg->decode_method != 2 && cfg->decode_method != 4 && cfg->decode_method != 5) return LNSFAID_E_INVAL;
     lnsfaid_oracle* o = (lnsfaid_oracle*)calloc(1, sizeof(*o));
     if (!o) return LNSFAID_E_NOMEM;
     o->code = *code;
@@ -208,7 +210,7 @@ static v32 oms_selective_offset(v32 x, int in_floor_window, m32 F, v32 factor_1,
 static void layered_iteration(lnsfaid_oracle* o, int nombre_iterations /* remaining after this one */, m32 l_m_error_sum)
 {
     const lnsfaid_cfg* c = &o->cfg;
-    const int oms = (c->decode_method == 1);
+    const int oms = (c->decode_method == 1 || c->decode_method == 4); /* Decode_OMS_DTBF shares Decode_OMS's loop */
     const int SAT_POS_VAR = 31, SAT_NEG_VAR = -31, SAT_POS_MSG = 7; /* Constants_SSE.h:20-25 */
     const v32 zero = v_set1(0);
     const v32 min_var = v_set1(SAT_NEG_VAR), max_var = v_set1(SAT_POS_VAR), max_msg = v_set1(SAT_POS_MSG);
@@ -390,7 +392,7 @@ static int bit_flipping(lnsfaid_oracle* o)
 static void decode_group(lnsfaid_oracle* o, const int8_t* fixInput, int8_t* decodedBits, lnsfaid_group_stats* st)
 {
     const lnsfaid_cfg* c = &o->cfg;
-    const int oms = (c->decode_method == 1);
+    const int oms = (c->decode_method == 1 || c->decode_method == 4);
     const v32 zero = v_set1(0);
     stage_input(o, fixInput);
 
@@ -410,7 +412,7 @@ static void decode_group(lnsfaid_oracle* o, const int8_t* fixInput, int8_t* deco
         executed++;
     }
     int bf = 0;
-    if (!oms) bf = bit_flipping(o);
+    if (c->decode_method != 1) bf = bit_flipping(o); /* Decode_OMS alone has no bit-flipping stage */
     /* uchar_itranspose_avx with LOAD_AND_DECIDE (CTool.cpp:291-575): out[l*N+v] = En[v][l] > 0 */
     const int N = o->code.n_var;
     for (int v = 0; v < N; ++v)

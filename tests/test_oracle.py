@@ -92,7 +92,8 @@ def test_count_errors_rule(abi, code50):
     assert cnt == [64, 3, 6, 2]
 
 
-@pytest.mark.parametrize("method,max_iter,eb_n0", [(2, 10, 3.5), (2, 10, 4.2), (1, 10, 3.6), (5, 10, 3.55), (2, 6, 3.6), (5, 3, 3.0)])
+@pytest.mark.parametrize("method,max_iter,eb_n0", [(2, 10, 3.5), (2, 10, 4.2), (1, 10, 3.6), (5, 10, 3.55), (2, 6, 3.6), (5, 3, 3.0),
+                                                   (4, 10, 3.6), (4, 4, 3.6)])
 def test_avx2_port_equals_oracle(abi, code50, method, max_iter, eb_n0):
     """The vectorised CPU port used as bench.py's cpu_baseline must agree bit for bit with the pinned oracle."""
     cfg = abi.default_cfg(method, max_iter)
@@ -140,3 +141,17 @@ def test_random_codewords_oracle_and_avx2_port(abi, code50, encoder):
     cnt = oa.Oracle(code50, cfg).count_errors(ref, inp, 2)
     err = (ref.reshape(64, code50.N)[:, :code50.K] != info).sum(axis=1)
     assert cnt == [64, int((err > 0).sum()), int(err.sum()), int(((err > 0) & (err < 3)).sum())]
+
+
+def test_method4_is_oms_followed_by_dtbf(abi, code50):
+    """DecodeMethod 4 (reference CDecoder_OMS_DTBF.cpp) has no recorded reference counters; its layered loop is textually
+    Decode_OMS's and its bit-flipping stage textually Decode_FAID's, both of which are pinned.  Consistency: with the
+    bit-flipping stage switched off it must equal DecodeMethod 1 exactly."""
+    fix = oa.ReferenceChannel(code50, 137, 13.0).groups(3.35, 4)
+    cfg4 = abi.default_cfg(4, 10)
+    cfg4.max_bf_iter = 0
+    a, sa = oa.decode_mt(code50, cfg4, fix, 4)
+    b, sb = oa.decode_mt(code50, abi.default_cfg(1, 10), fix, 4)
+    assert np.array_equal(a, b) and np.array_equal(sa, sb)
+    c, sc = oa.decode_mt(code50, abi.default_cfg(4, 10), fix, 4)
+    assert sc[:, 1].max() > 0 and not np.array_equal(c, b)  # the flipping stage does change frames at this Eb/N0
