@@ -6,6 +6,8 @@
  *   void CLDPC::Decode_OMS()        (reference CLDPC.h:148, CDecoder_OMS.cpp:13)
  *   void CLDPC::Decode_FAID()       (reference CLDPC.h:149, CDecoder_FAID.cpp:176)
  *   void CLDPC::Decode_FAID_2B1C()  (reference CLDPC.h:152, CDecoder_FAID_2B1C.cpp:96)
+ *   int  CLDPC::Decode_OMSBF()      (reference CLDPC.h:150, CDecoder_OMSBF.cpp:13; DecodeMethod 3: the layered loop of
+ *                                    Decode_OMS followed by plain bit flipping with threshold min(max vote, 5))
  *   int  CLDPC::Decode_OMS_DTBF()   (reference CLDPC.h:151, CDecoder_OMS_DTBF.cpp:18; DecodeMethod 4: the layered
  *                                    loop of Decode_OMS followed by the DTBF stage of Decode_FAID with other constants)
  *   Statistic CLDPC::CalculateErrors(...) (reference CLDPC.h:169, CLDPC.cpp:4819)
@@ -70,7 +72,7 @@ typedef struct lnsfaid_code {
  * shipped values for a DecodeMethod.
  */
 typedef struct lnsfaid_cfg {
-    int32_t decode_method;     /* Profile.txt DecodeMethod: 1, 2, 4 or 5 (README.md:13) */
+    int32_t decode_method;     /* Profile.txt DecodeMethod: 1, 2, 3, 4 or 5 (README.md:13) */
     int32_t max_iteration;     /* Profile.txt MaxIteration (nb_iteration)           */
     int32_t factor_1;          /* Profile.txt Factor_1 (selective offset, OMS)      */
     int32_t factor_2;          /* Profile.txt Factor_2                              */
@@ -84,6 +86,7 @@ typedef struct lnsfaid_cfg {
     int32_t bf_delta;          /* _delta 1                                           */
     int32_t regular_col_weight;/* REGULAR_COL_WEIGHT 3 (CTool.h:6)                   */
     int32_t hard2_threshold;   /* 13 (CDecoder_FAID_2B1C.cpp:6130)                   */
+    int32_t bf_vote_cap;       /* 5: plain BF flips votes >= min(max_vote, 5) (CDecoder_OMSBF.cpp:3332) */
     /* V2C_map_it{1..6}_[weight class 3,6,11,other][min(|t|,7)] (CDecoder_FAID.cpp:12-49) */
     int8_t v2c_map[6][4][8];
     /* V2C_map_it{1..6}_ef (CDecoder_FAID.cpp:130-165) */
@@ -105,7 +108,7 @@ typedef struct lnsfaid_ctx lnsfaid_ctx;
  * entries.  Returns LNSFAID_OK. */
 int lnsfaid_code_50gpon(lnsfaid_code* code, uint16_t* pos_vn, int32_t* deg3, int32_t* deg_rows3);
 
-/* Fill `cfg` with the reference's shipped constants for DecodeMethod 1, 2, 4 or 5. */
+/* Fill `cfg` with the reference's shipped constants for DecodeMethod 1, 2, 3, 4 or 5. */
 int lnsfaid_cfg_default(lnsfaid_cfg* cfg, int32_t decode_method, int32_t max_iteration);
 
 /* ---- decoder context --------------------------------------------------------- */

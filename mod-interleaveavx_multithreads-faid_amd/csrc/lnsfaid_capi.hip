@@ -139,7 +139,7 @@ static void build_wcols(LfDevCode* code, int W)
 static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
 {
     if (!cfg) return LNSFAID_E_INVAL;
-    if (cfg->decode_method != 1 && cfg->decode_method != 2 && cfg->decode_method != 4 && cfg->decode_method != 5) return LNSFAID_E_INVAL;
+    if (cfg->decode_method < 1 || cfg->decode_method > 5) return LNSFAID_E_INVAL;
     if (cfg->max_iteration < 0 || cfg->max_iteration > (1 << 20)) return LNSFAID_E_INVAL;
     if (cfg->max_bf_iter < 0 || cfg->max_bf_iter > (1 << 20)) return LNSFAID_E_INVAL;
     if (cfg->regular_col_weight < 0 || cfg->regular_col_weight > LF_MAX_COLW) return LNSFAID_E_INVAL;
@@ -155,6 +155,7 @@ static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
     out->L0 = cfg->bf_L0; out->L1 = cfg->bf_L1; out->alpha = cfg->bf_alpha; out->delta = cfg->bf_delta;
     out->W = cfg->regular_col_weight;
     out->hard2_thr = cfg->hard2_threshold;
+    out->vote_cap = (int8_t)cfg->bf_vote_cap;
     if (cfg->decode_method == 5 && cfg->ef_elimination != 1) return LNSFAID_E_INVAL;
     if (cfg->decode_method == 2 && cfg->ef_elimination != 0) return LNSFAID_E_INVAL;
     out->uniform_w = 1;
@@ -162,7 +163,7 @@ static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
         for (int w = 0; w < 4; ++w) {
             for (int a = 0; a < 8; ++a) {
                 const int v = cfg->v2c_map[it][w][a], ve = cfg->v2c_map_ef[it][w][a];
-                if (cfg->decode_method != 1 && cfg->decode_method != 4 && (v < 0 || v > 7)) return LNSFAID_E_INVAL; /* 3-bit message alphabet */
+                if ((cfg->decode_method == 2 || cfg->decode_method == 5) && (v < 0 || v > 7)) return LNSFAID_E_INVAL; /* 3-bit message alphabet */
                 if (cfg->decode_method == 5 && (ve < 0 || ve > 7)) return LNSFAID_E_INVAL;
                 uint32_t* l = a < 4 ? &out->lut_lo[it][w] : &out->lut_hi[it][w];
                 uint32_t* le = a < 4 ? &out->lut_ef_lo[it][w] : &out->lut_ef_hi[it][w];
@@ -204,6 +205,9 @@ static int create_impl(lnsfaid_ctx* ctx, const lnsfaid_code* code, const lnsfaid
     rc = build_cfg(cfg, &ctx->hcfg);
     if (rc) return rc;
     ctx->n_var = ctx->hcode.n_var; ctx->n_check = ctx->hcode.n_check; ctx->k_info = ctx->hcode.k_info;
+    if (ctx->hcfg.method == 3)
+        for (int cb = 0; cb < ctx->hcode.nbc; ++cb)
+            if (ctx->hcode.col_weight[cb] > 15) return LNSFAID_E_CODE; /* plain BF counts votes in 4 bit planes */
     build_wcols(&ctx->hcode, ctx->hcfg.W);
     ctx->lds_bytes = lf_lds_bytes(ctx->n_var, ctx->hcode.n_words, ctx->hcode.p_words);
     if (ctx->lds_bytes > 64 * 1024) return LNSFAID_E_CODE;

@@ -39,7 +39,7 @@ struct LfDevCode {
 
 struct LfDevCfg {
     int32_t method, max_iter, factor_1, factor_2, floor_err_count, floor_iter_thresh, ef, max_bf;
-    int32_t L0, L1, alpha, delta, W, hard2_thr;
+    int32_t L0, L1, alpha, delta, W, hard2_thr, vote_cap;
     int32_t uniform_w; /* all four weight classes carry the same table rows (true for every shipped set)      */
     int32_t bf_fast;   /* W == 3 and alpha in {0, 1}: bit-sliced flip decision                                */
     /* V2C_map_it{1..6}_[class] as 8 bytes for v_perm_b32: lo = entries 0..3, hi = entries 4..7 */

@@ -37,6 +37,9 @@
 
 #include "lnsfaid_device.h"
 
+/* DecodeMethods whose layered loop is Decode_OMS's: 1 (alone), 3 (+ plain bit flipping), 4 (+ DTBF) */
+#define LF_OMS(M) ((M) == 1 || (M) == 3 || (M) == 4)
+
 #define SAT_POS_VAR 31 /* Constants_SSE.h:22 */
 #define SAT_NEG_VAR (-31)
 #define SAT_POS_MSG 7  /* Constants_SSE.h:24 */
@@ -264,7 +267,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             const uint32_t nb = ((j < 16 ? XL : XH) >> (j & 15)) & 0x00010001u;
             s2 t = pk_max(pk_mad_i(pk_2b_minus_1(nb), S(U(mag)), E), (s2)(SAT_NEG_VAR)); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
             s2 yy;
-            if (METHOD == 1 || METHOD == 4) {
+            if (LF_OMS(METHOD)) {
                 yy = pk_mad_i(t, S(c64), S(0x00200020u)); /* 64 t + 32: sign(yy) = (t < 0), CDecoder_OMS.cpp:372 */
             } else {
                 t = pk_min(t, (s2)(SAT_POS_VAR)); /* CDecoder_FAID.cpp:672 */
@@ -274,7 +277,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             sx ^= U(yy);
             const s2 a = pk_min(pk_max(t, (s2)(0) - t), (s2)(SAT_POS_MSG)); /* |t| >= 8 maps through column 7 */
             uint32_t m;
-            if (METHOD == 1 || METHOD == 4) {
+            if (LF_OMS(METHOD)) {
                 m = U(a); /* CDecoder_OMS.cpp:374 */
             } else {
                 if (!UNIW) {
@@ -298,7 +301,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     const u2 min1 = k1 >> (u2)(8), min2 = k2 >> (u2)(8);
     const uint32_t JM = U(k1) & 0x00ff00ffu;
     u2 C1n, C2n;
-    if (METHOD == 1 || METHOD == 4) {
+    if (LF_OMS(METHOD)) {
         const bool FA = prA && lme, FB = prB && lme;
         const int a1 = imin(oms_offset(min2.x, window, FA, f1, f2), SAT_POS_MSG); /* cste_1, CDecoder_OMS.cpp:431 */
         const int a2 = imin(oms_offset(min1.x, window, FA, f1, f2), SAT_POS_MSG); /* cste_2 */
@@ -321,7 +324,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     for (int j = 0; j < NJ; ++j) {
         if (DEG > 0 || j < deg) {
             const s2 yy = S(y[j]);
-            const s2 t = (METHOD == 1 || METHOD == 4) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
+            const s2 t = (LF_OMS(METHOD)) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
             const u2 ne = pk_nonzero(JM ^ JJ(j));
             const u2 mag = pk_mad(ne, DCn, C1n);
             const uint32_t sb = U(US(U(yy)) >> (u2)(15)); /* raw sign s_j per half */
@@ -467,6 +470,76 @@ __device__ void bf_step(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, c
     ls.t = block_sum2(anyw != 0ull ? 1 : 0, tid, sRed) != 0; /* barriers also order the plane updates */
 }
 
+/* ---- plain bit flipping of Decode_OMSBF (CDecoder_OMSBF.cpp:2969-3514): flip every variable node whose vote count
+ * reaches min(max vote of the frame, cap).  Votes of all block columns are counted bit-sliced (4 planes, column
+ * weight <= 15), the frame's maximum is found from "some count >= k" flags, then the planes are compared with the
+ * threshold. */
+__device__ __forceinline__ uint32_t votes_ge(uint32_t c3, uint32_t c2, uint32_t c1, uint32_t c0, int k)
+{
+    /* bitwise 4-bit comparator: count < k, scanned from the most significant plane */
+    uint32_t lt = 0u, eqm = 0xffffffffu;
+    const uint32_t pl[4] = { c0, c1, c2, c3 };
+#pragma unroll
+    for (int b = 3; b >= 0; --b) {
+        if ((k >> b) & 1) { lt |= eqm & ~pl[b]; eqm &= pl[b]; }
+        else eqm &= ~pl[b];
+    }
+    return ~lt;
+}
+
+__device__ void bf_step_plain(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, uint32_t* sCnt, const uint32_t* sP, int tid,
+                              int* sRed)
+{
+    const int nw = c->n_words;
+    const int units = c->nbc * 4;
+    uint32_t seen = 0; /* bit k: some variable node of this lane's units has >= k votes (k = 1..15) */
+    for (int u = tid; u < units; u += LF_T) {
+        const int cb = u >> 2;
+        const uint32_t win = (uint32_t)(u & 3);
+        const int wgt = gc->col_weight[cb];
+        uint32_t c0[2] = { 0u, 0u }, c1[2] = { 0u, 0u }, c2[2] = { 0u, 0u }, c3[2] = { 0u, 0u };
+        for (int k = 0; k < wgt; ++k) {
+            const uint32_t cc = gc->colcirc[cb][k];
+            uint32_t x[2];
+            window64(sP + (cc & 0xffu) * 8u, (64u * win - ((cc >> 8) & 0xffu)) & 255u, x[0], x[1]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { /* ripple-carry increment of the 4-bit counters where x is set */
+                uint32_t carry = x[h], t;
+                t = c0[h] & carry; c0[h] ^= carry; carry = t;
+                t = c1[h] & carry; c1[h] ^= carry; carry = t;
+                t = c2[h] & carry; c2[h] ^= carry; carry = t;
+                c3[h] ^= carry;
+            }
+        }
+        const int w0 = cb * 8 + 2 * (int)win;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            sCnt[w0 + h] = c0[h]; sCnt[nw + w0 + h] = c1[h]; sCnt[2 * nw + w0 + h] = c2[h]; sCnt[3 * nw + w0 + h] = c3[h];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) seen |= (votes_ge(c3[h], c2[h], c1[h], c0[h], k) != 0u) ? (1u << k) : 0u;
+        }
+    }
+    /* OR of `seen` over the workgroup */
+    for (int o = 32; o > 0; o >>= 1) seen |= (uint32_t)__shfl_xor((int)seen, o);
+    if ((tid & 63) == 0) sRed[tid >> 6] = (int)seen;
+    __syncthreads();
+    seen = (uint32_t)sRed[0] | (uint32_t)sRed[1];
+    __syncthreads();
+    const int max_vote = seen ? 31 - __clz((int)seen) : 1; /* max_vote starts at 1 (CDecoder_OMSBF.cpp:2975) */
+    const int thr = imin(imax(max_vote, 1), (int)(int8_t)f->vote_cap);
+    for (int u = tid; u < units; u += LF_T) {
+        const int w0 = (u >> 2) * 8 + 2 * (u & 3);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t m = 0xffffffffu; /* thr <= 0: every vote count qualifies */
+            if (thr >= 16) m = 0u;
+            else if (thr > 0) m = votes_ge(sCnt[3 * nw + w0 + h], sCnt[2 * nw + w0 + h], sCnt[nw + w0 + h], sCnt[w0 + h], thr);
+            sHard[w0 + h] ^= m;
+        }
+    }
+    __syncthreads();
+}
+
 /* ---- the decode kernel: one workgroup per codeword ---------------------------------------------------- */
 template <int METHOD, bool UNIW>
 __global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
@@ -584,7 +657,7 @@ __global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
                     build_plane<false>(c, sEn, sHard, 0, tid);
                     const int unsat = syndrome(c, a.code, sHard, sP, tid, pA, pB, sRed);
                     if (unsat == 0 && prog >= kmax) break; /* clean on the group's front: park */
-                    if (METHOD == 1 || METHOD == 4) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
+                    if (LF_OMS(METHOD)) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
                     else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
                 }
                 main_step<METHOD, UNIW>(c, f, sEn, g_rows, tid, prog, pA, pB, lme);
@@ -592,7 +665,8 @@ __global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
             } else {
                 const int unsat = syndrome(c, a.code, sHard, sP, tid, pA, pB, sRed);
                 if (unsat == 0 && prog >= kmax) break;
-                bf_step<METHOD>(c, f, a.code, sHard, sHard0, sHard2, sP, tid, ls, sRed);
+                if (METHOD == 3) bf_step_plain(c, f, a.code, sHard, sHard2 + nw /* 4 count planes in the dead En */, sP, tid, sRed);
+                else bf_step<METHOD>(c, f, a.code, sHard, sHard0, sHard2, sP, tid, ls, sRed);
                 prog++;
             }
         }
@@ -705,6 +779,7 @@ extern "C" hipError_t lf_launch_decode(int method, int uniform_w, const LfKernel
     switch (method) {
     case 1: return launch_method<1>(true, args, lds_bytes, stream); /* OMS has no look-up table */
     case 2: return launch_method<2>(uniform_w != 0, args, lds_bytes, stream);
+    case 3: return launch_method<3>(true, args, lds_bytes, stream); /* OMS arithmetic + plain bit flipping */
     case 4: return launch_method<4>(true, args, lds_bytes, stream); /* OMS arithmetic + DTBF */
     case 5: return launch_method<5>(uniform_w != 0, args, lds_bytes, stream);
     default: return hipErrorInvalidValue;

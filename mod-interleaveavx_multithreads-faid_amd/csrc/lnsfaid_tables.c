@@ -94,6 +94,7 @@ int lnsfaid_cfg_default(lnsfaid_cfg* cfg, int32_t decode_method, int32_t max_ite
     cfg->bf_delta = 1; /* _delta CDecoder_FAID.cpp:167 */
     cfg->regular_col_weight = 3; /* CTool.h:6 */
     cfg->hard2_threshold = 13;   /* CDecoder_FAID_2B1C.cpp:6130 */
+    cfg->bf_vote_cap = 5;        /* CDecoder_OMSBF.cpp:3332 */
     for (int it = 0; it < 6; ++it) fill_map(cfg->v2c_map_ef[it], ef);
     switch (decode_method) {
     case 1: /* Decode_OMS */
@@ -103,6 +104,13 @@ int lnsfaid_cfg_default(lnsfaid_cfg* cfg, int32_t decode_method, int32_t max_ite
         cfg->max_bf_iter = 0;        /* no bit flipping stage */
         cfg->bf_L0 = 0;
         for (int it = 0; it < 6; ++it) fill_map(cfg->v2c_map[it], ident); /* min(|t|,7), CDecoder_OMS.cpp:374 */
+        break;
+    case 3: /* Decode_OMSBF: the OMS layered loop followed by plain bit flipping */
+        cfg->floor_err_count = 100;  /* CDecoder_OMSBF.cpp:28 */
+        cfg->floor_iter_thresh = 4;  /* CDecoder_OMSBF.cpp:29 */
+        cfg->ef_elimination = 0;
+        cfg->max_bf_iter = 50;       /* CDecoder_OMSBF.cpp:30 */
+        for (int it = 0; it < 6; ++it) fill_map(cfg->v2c_map[it], ident);
         break;
     case 4: /* Decode_OMS_DTBF: the OMS layered loop followed by the DTBF stage with its own constants */
         cfg->floor_err_count = 100;  /* CDecoder_OMS_DTBF.cpp:33 */

@@ -124,6 +124,7 @@ uint64_t CLDPC::DrawsPerGroup(int mod_type)
 void CLDPC::Decode_OMS() { decode_with(1); }
 void CLDPC::Decode_FAID() { decode_with(2); }
 void CLDPC::Decode_FAID_2B1C() { decode_with(5); }
+int CLDPC::Decode_OMSBF() { decode_with(3); return m_device_io ? 0 : m_stats[0].bf_iterations; }
 int CLDPC::Decode_OMS_DTBF() { decode_with(4); return m_device_io ? 0 : m_stats[0].bf_iterations; }
 
 Statistic CLDPC::CalculateErrors()

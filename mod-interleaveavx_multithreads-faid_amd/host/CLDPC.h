@@ -47,6 +47,7 @@ public:
     void Decode_OMS();       /* DecodeMethod 1 */
     void Decode_FAID();      /* DecodeMethod 2 */
     void Decode_FAID_2B1C(); /* DecodeMethod 5 */
+    int Decode_OMSBF();      /* DecodeMethod 3; returns the bit-flipping iterations of the first group */
     int Decode_OMS_DTBF();   /* DecodeMethod 4; returns the bit-flipping iterations of the first group (reference: BFiter) */
     Statistic CalculateErrors();
 

@@ -141,10 +141,11 @@ void CSimulate::Run()
         switch (decode_method) { /* reference CSimulate.cpp:136-164 */
         case 1: ldpc->Decode_OMS(); break;
         case 2: ldpc->Decode_FAID(); break;
+        case 3: (void)ldpc->Decode_OMSBF(); break;
         case 4: (void)ldpc->Decode_OMS_DTBF(); break;
         case 5: ldpc->Decode_FAID_2B1C(); break;
         default:
-            fprintf(stderr, "DecodeMethod %d is not implemented on this path (1, 2, 4, 5 are)\n", decode_method);
+            fprintf(stderr, "DecodeMethod %d is not implemented on this path (1, 2, 3, 4, 5 are)\n", decode_method);
             exit(EXIT_FAILURE);
         }
         decode_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

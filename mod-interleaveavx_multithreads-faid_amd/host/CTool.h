@@ -14,7 +14,7 @@ struct Parameter_Simulation {
     float snr_pass;  /* SNRPass  */
     float snr_end;   /* EndSNR   */
     float scale;     /* scale: quantiser scale */
-    int decode_method; /* DecodeMethod: 1 OMS, 2 FAID+DTBF, 4 OMS+DTBF, 5 FAID+2B1C (reference README.md:13) */
+    int decode_method; /* DecodeMethod: 1 OMS, 2 FAID+DTBF, 3 OMS+BF, 4 OMS+DTBF, 5 FAID+2B1C (reference README.md:13) */
     int Max_Iteration; /* MaxIteration */
     int mod_type;      /* modType: 1 BPSK, 2 QPSK */
     int interleavemod_type; /* InterleaveModType */

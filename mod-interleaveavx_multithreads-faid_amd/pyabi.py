@@ -44,6 +44,7 @@ class Cfg(C.Structure):
         ("bf_delta", C.c_int32),
         ("regular_col_weight", C.c_int32),
         ("hard2_threshold", C.c_int32),
+        ("bf_vote_cap", C.c_int32),
         ("v2c_map", C.c_int8 * 8 * 4 * 6),
         ("v2c_map_ef", C.c_int8 * 8 * 4 * 6),
     ]

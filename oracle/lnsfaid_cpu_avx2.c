@@ -40,7 +40,7 @@ static inline V sel(V mask, V a, V b) { return _mm256_blendv_epi8(b, a, mask); }
 int lnsfaid_cpu_create(lnsfaid_cpu** out, const lnsfaid_code* code, const lnsfaid_cfg* cfg)
 {
     if (!out || !code || !cfg || !code->pos_vn) return LNSFAID_E_INVAL;
-    if (cfg->decode_method != 1 && cfg->decode_method != 2 && cfg->decode_method != 4 && cfg->decode_method != 5) return LNSFAID_E_INVAL;
+    if (cfg->decode_method < 1 || cfg->decode_method > 5) return LNSFAID_E_INVAL;
     lnsfaid_cpu* o = (lnsfaid_cpu*)calloc(1, sizeof(*o));
     if (!o) return LNSFAID_E_NOMEM;
     o->code = *code;
@@ -114,7 +114,7 @@ static void decode_group(lnsfaid_cpu* o, const int8_t* fix, int8_t* out, lnsfaid
 {
     const lnsfaid_cfg* c = &o->cfg;
     const int N = o->code.n_var, M = o->code.n_check, K = N - M, E = o->code.n_edges;
-    const int oms = c->decode_method == 1 || c->decode_method == 4, ef = c->ef_elimination >= 1;
+    const int oms = c->decode_method == 1 || c->decode_method == 3 || c->decode_method == 4, ef = c->ef_elimination >= 1;
     const int with_bf = c->decode_method != 1;
     const V zero = _mm256_setzero_si256(), one = set1(1), ones = set1(-1);
     const V vmin = set1(-31), vmax = set1(31), v7 = set1(7), sbit = set1((char)0x80);
@@ -210,7 +210,31 @@ static void decode_group(lnsfaid_cpu* o, const int8_t* fix, int8_t* out, lnsfaid
     }
 
     int bf = 0;
-    if (with_bf) {
+    if (c->decode_method == 3) { /* plain bit flipping, CDecoder_OMSBF.cpp:2959-3517 */
+        for (int i = 0; i < N; ++i) { o->hard[i] = gt(o->En[i], zero); o->flip[i] = zero; }
+        while (bf < c->max_bf_iter) {
+            for (int i = 0; i < N; ++i) o->vote[i] = zero;
+            V esum = zero, maxv = one;
+            const uint16_t* p = o->pos;
+            const uint16_t* p2 = o->pos;
+            for (int r = 0; r < M; ++r) {
+                V par = zero;
+                for (int j = 0; j < o->row_deg[r]; ++j) par = _mm256_xor_si256(par, o->hard[*p++]);
+                const V inc = _mm256_and_si256(par, one);
+                esum = _mm256_adds_epu8(esum, inc);
+                for (int j = 0; j < o->row_deg[r]; ++j, ++p2) {
+                    o->vote[*p2] = _mm256_adds_epu8(o->vote[*p2], inc);
+                    maxv = _mm256_max_epi8(maxv, o->vote[*p2]);
+                }
+            }
+            if (_mm256_testz_si256(esum, esum)) break;
+            const V thr = _mm256_min_epi8(maxv, set1(c->bf_vote_cap));
+            for (int v = 0; v < N; ++v)
+                if (o->vn_weight[v] > 0) o->flip[v] = _mm256_or_si256(gt(o->vote[v], thr), eq(o->vote[v], thr));
+            for (int i = 0; i < N; ++i) o->hard[i] = _mm256_xor_si256(o->hard[i], o->flip[i]);
+            bf++;
+        }
+    } else if (with_bf) {
         const int W = c->regular_col_weight, two_bit = c->decode_method == 5;
         const V thr = set1(c->hard2_threshold), nthr = set1(-c->hard2_threshold);
         for (int i = 0; i < N; ++i) {

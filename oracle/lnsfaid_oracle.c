@@ -11,6 +11,7 @@
  *   - Decode_OMS        reference CDecoder_OMS.cpp:13-2998      (DecodeMethod 1)
  *   - Decode_FAID       reference CDecoder_FAID.cpp:176-7135    (DecodeMethod 2, FAID + DTBF)
  *   - Decode_FAID_2B1C  reference CDecoder_FAID_2B1C.cpp:96-6866 (DecodeMethod 5)
+ *   - Decode_OMSBF      reference CDecoder_OMSBF.cpp:13-3557     (DecodeMethod 3: Decode_OMS's loop + plain bit flipping)
  *   - Decode_OMS_DTBF   reference CDecoder_OMS_DTBF.cpp:18-3692  (DecodeMethod 4: its layered loop is textually
  *                       Decode_OMS's and its bit-flipping stage textually Decode_FAID's, checked by diff)
  *   - CalculateErrors   reference CLDPC.cpp:4842-4876
@@ -99,7 +100,7 @@ struct lnsfaid_oracle {
 int lnsfaid_oracle_create(lnsfaid_oracle** out, const lnsfaid_code* code, const lnsfaid_cfg* cfg)
 {
     if (!out || !code || !cfg || !code->pos_vn) return LNSFAID_E_INVAL;
-    if (cfg->decode_method != 1 && cfg->decode_method != 2 && cfg->decode_method != 4 && cfg->decode_method != 5) return LNSFAID_E_INVAL;
+    if (cfg->decode_method < 1 || cfg->decode_method > 5) return LNSFAID_E_INVAL;
     lnsfaid_oracle* o = (lnsfaid_oracle*)calloc(1, sizeof(*o));
     if (!o) return LNSFAID_E_NOMEM;
     o->code = *code;
@@ -210,7 +211,7 @@ static v32 oms_selective_offset(v32 x, int in_floor_window, m32 F, v32 factor_1,
 static void layered_iteration(lnsfaid_oracle* o, int nombre_iterations /* remaining after this one */, m32 l_m_error_sum)
 {
     const lnsfaid_cfg* c = &o->cfg;
-    const int oms = (c->decode_method == 1 || c->decode_method == 4); /* Decode_OMS_DTBF shares Decode_OMS's loop */
+    const int oms = (c->decode_method == 1 || c->decode_method == 3 || c->decode_method == 4); /* Decode_OMSBF / Decode_OMS_DTBF share Decode_OMS's loop */
     const int SAT_POS_VAR = 31, SAT_NEG_VAR = -31, SAT_POS_MSG = 7; /* Constants_SSE.h:20-25 */
     const v32 zero = v_set1(0);
     const v32 min_var = v_set1(SAT_NEG_VAR), max_var = v_set1(SAT_POS_VAR), max_msg = v_set1(SAT_POS_MSG);
@@ -388,11 +389,48 @@ static int bit_flipping(lnsfaid_oracle* o)
     return BFiter;
 }
 
+/* Plain bit flipping of Decode_OMSBF (CDecoder_OMSBF.cpp:2959-3517): every variable node whose number of
+ * unsatisfied checks reaches min(max vote of the frame, 5) is flipped; group-wide break as everywhere. */
+static int bit_flipping_plain(lnsfaid_oracle* o)
+{
+    const lnsfaid_cfg* c = &o->cfg;
+    const int N = o->code.n_var;
+    const v32 zero = v_set1(0), ones = v_set1(1);
+    for (int i = 0; i < N; ++i) { o->hard_llr[i] = m_gt(o->var_nodes[i], zero); o->flip_record[i] = 0; }
+    int BFiter = 0;
+    while (BFiter < c->max_bf_iter) {
+        for (int i = 0; i < N; ++i) o->flip_vote[i] = zero;
+        v32 max_vote = ones; /* "cannot be 0, otherwise all correct answers would flip" (:2975) */
+        v32 error_sum = zero;
+        const uint16_t* pCN = o->pos_vn;
+        const uint16_t* pCN2 = o->pos_vn;
+        for (int r = 0; r < o->code.n_check; ++r) {
+            m32 mask_sum = 0;
+            for (int j = 0; j < o->row_deg[r]; ++j) mask_sum ^= o->hard_llr[*pCN++];
+            o->checksum[r] = mask_sum;
+            error_sum = v_addu_mask(mask_sum, error_sum, ones);
+            for (int j = 0; j < o->row_deg[r]; ++j) {
+                o->flip_vote[*pCN2] = v_addu_mask(mask_sum, o->flip_vote[*pCN2], ones);
+                max_vote = v_max(max_vote, o->flip_vote[*pCN2]);
+                pCN2++;
+            }
+        }
+        if (m_gtu(error_sum, zero) == 0) break; /* :3321 */
+        const v32 thr = v_min(max_vote, v_set1(c->bf_vote_cap));
+        pCN2 = o->pos_vn;
+        for (int k = 0; k < o->code.n_edges; ++k, ++pCN2) o->flip_record[*pCN2] = m_ge(o->flip_vote[*pCN2], thr); /* :3332 */
+        for (int i = 0; i < N; ++i) o->hard_llr[i] ^= o->flip_record[i]; /* :3511-3513 */
+        BFiter++;
+    }
+    for (int i = 0; i < N; ++i) o->var_nodes[i] = v_mov_mask(v_set1(-1), o->hard_llr[i], ones);
+    return BFiter;
+}
+
 /* One reference Decode_*() call = one group of 32 frames. */
 static void decode_group(lnsfaid_oracle* o, const int8_t* fixInput, int8_t* decodedBits, lnsfaid_group_stats* st)
 {
     const lnsfaid_cfg* c = &o->cfg;
-    const int oms = (c->decode_method == 1 || c->decode_method == 4);
+    const int oms = (c->decode_method == 1 || c->decode_method == 3 || c->decode_method == 4);
     const v32 zero = v_set1(0);
     stage_input(o, fixInput);
 
@@ -412,7 +450,8 @@ static void decode_group(lnsfaid_oracle* o, const int8_t* fixInput, int8_t* deco
         executed++;
     }
     int bf = 0;
-    if (c->decode_method != 1) bf = bit_flipping(o); /* Decode_OMS alone has no bit-flipping stage */
+    if (c->decode_method == 3) bf = bit_flipping_plain(o);
+    else if (c->decode_method != 1) bf = bit_flipping(o); /* Decode_OMS alone has no bit-flipping stage */
     /* uchar_itranspose_avx with LOAD_AND_DECIDE (CTool.cpp:291-575): out[l*N+v] = En[v][l] > 0 */
     const int N = o->code.n_var;
     for (int v = 0; v < N; ++v)

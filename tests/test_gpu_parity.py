@@ -27,12 +27,12 @@ def _parity(abi, code50, method, max_iter, eb_n0, n_groups, seed=101, codeword=N
     return out, stats
 
 
-@pytest.mark.parametrize("method", [2, 1, 5, 4])
+@pytest.mark.parametrize("method", [2, 1, 5, 4, 3])
 @pytest.mark.parametrize("eb_n0", [3.5, 4.2, 3.0])
 def test_decode_matches_oracle(abi, code50, method, eb_n0):
     _parity(abi, code50, method, 10, eb_n0, 4)
 
 
-@pytest.mark.parametrize("method,max_iter", [(2, 6), (2, 1), (2, 0), (1, 3), (5, 7), (1, 0), (4, 5), (4, 0)])
+@pytest.mark.parametrize("method,max_iter", [(2, 6), (2, 1), (2, 0), (1, 3), (5, 7), (1, 0), (4, 5), (4, 0), (3, 4), (3, 0)])
 def test_iteration_caps(abi, code50, method, max_iter):
     _parity(abi, code50, method, max_iter, 3.6, 2, seed=103)

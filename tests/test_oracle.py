@@ -93,7 +93,7 @@ def test_count_errors_rule(abi, code50):
 
 
 @pytest.mark.parametrize("method,max_iter,eb_n0", [(2, 10, 3.5), (2, 10, 4.2), (1, 10, 3.6), (5, 10, 3.55), (2, 6, 3.6), (5, 3, 3.0),
-                                                   (4, 10, 3.6), (4, 4, 3.6)])
+                                                   (4, 10, 3.6), (4, 4, 3.6), (3, 10, 3.4), (3, 3, 3.6)])
 def test_avx2_port_equals_oracle(abi, code50, method, max_iter, eb_n0):
     """The vectorised CPU port used as bench.py's cpu_baseline must agree bit for bit with the pinned oracle."""
     cfg = abi.default_cfg(method, max_iter)
@@ -155,3 +155,10 @@ def test_method4_is_oms_followed_by_dtbf(abi, code50):
     assert np.array_equal(a, b) and np.array_equal(sa, sb)
     c, sc = oa.decode_mt(code50, abi.default_cfg(4, 10), fix, 4)
     assert sc[:, 1].max() > 0 and not np.array_equal(c, b)  # the flipping stage does change frames at this Eb/N0
+    # DecodeMethod 3 (Decode_OMSBF): same relation to DecodeMethod 1
+    cfg3 = abi.default_cfg(3, 10)
+    cfg3.max_bf_iter = 0
+    a3, s3 = oa.decode_mt(code50, cfg3, fix, 4)
+    assert np.array_equal(a3, b) and np.array_equal(s3, sb)
+    c3, sc3 = oa.decode_mt(code50, abi.default_cfg(3, 10), fix, 4)
+    assert sc3[:, 1].max() > 0 and not np.array_equal(c3, b)

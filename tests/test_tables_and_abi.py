@@ -66,10 +66,12 @@ def test_default_configurations_match_the_reference_constants(abi, lib):
                 assert list(c.v2c_map_ef[it][w]) == ef
     c = abi.default_cfg(1, 10, lib)
     assert (c.floor_err_count, c.floor_iter_thresh, c.max_bf_iter) == (100, 4, 0)
+    c = abi.default_cfg(3, 10, lib)  # CDecoder_OMSBF.cpp:28-30, :3332
+    assert (c.floor_err_count, c.floor_iter_thresh, c.max_bf_iter, c.bf_vote_cap) == (100, 4, 50, 5)
     c = abi.default_cfg(4, 10, lib)  # CDecoder_OMS_DTBF.cpp:6-9, :33-35
     assert (c.floor_err_count, c.floor_iter_thresh, c.max_bf_iter, c.bf_L0, c.bf_L1, c.bf_alpha, c.bf_delta) == (100, 4, 50, 0, 50, 1, 1)
     bad = abi.Cfg()
-    assert lib.lnsfaid_cfg_default(C.byref(bad), 3, 10) != 0  # DecodeMethod 3 is not on this path
+    assert lib.lnsfaid_cfg_default(C.byref(bad), 0, 10) != 0  # DecodeMethod 0 (NMS) is not on this path
 
 
 def test_library_exports_every_symbol_of_the_header(abi, lib):
