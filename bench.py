@@ -187,7 +187,7 @@ def main():
             "workload": "50G-PON N=17664 K=14592 Z=256, %s all-zero codeword + AWGN, DecodeMethod=%d (%s), "
                         "MaxIteration=%d, scale %g, %d codewords (%d groups of 32) per GPU, Eb/N0 %.1f dB"
                         % ({2: "QPSK", 4: "16-QAM"}[args.mod_type], args.method,
-                           {1: "OMS", 2: "3-bit LNS-FAID FAID3 + DTBF", 3: "OMS + BF", 4: "OMS + DTBF", 5: "FAID + 2B1C"}[args.method],
+                           {0: "NMS", 1: "OMS", 2: "3-bit LNS-FAID FAID3 + DTBF", 3: "OMS + BF", 4: "OMS + DTBF", 5: "FAID + 2B1C"}[args.method],
                            args.max_iter, args.scale, n_cw, n_groups, args.eb_n0),
             "eb_n0_db": args.eb_n0,
             "mean_layered_iterations": head["mean_I"],

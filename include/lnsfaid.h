@@ -6,6 +6,8 @@
  *   void CLDPC::Decode_OMS()        (reference CLDPC.h:148, CDecoder_OMS.cpp:13)
  *   void CLDPC::Decode_FAID()       (reference CLDPC.h:149, CDecoder_FAID.cpp:176)
  *   void CLDPC::Decode_FAID_2B1C()  (reference CLDPC.h:152, CDecoder_FAID_2B1C.cpp:96)
+ *   void CLDPC::Decode()            (reference CLDPC.h:146, CLDPC.cpp:214; DecodeMethod 0 / default: normalised min-sum,
+ *                                    Factor_1 / Factor_2 are numerators over 32, fixed iteration count, no early stop)
  *   int  CLDPC::Decode_OMSBF()      (reference CLDPC.h:150, CDecoder_OMSBF.cpp:13; DecodeMethod 3: the layered loop of
  *                                    Decode_OMS followed by plain bit flipping with threshold min(max vote, 5))
  *   int  CLDPC::Decode_OMS_DTBF()   (reference CLDPC.h:151, CDecoder_OMS_DTBF.cpp:18; DecodeMethod 4: the layered
@@ -72,7 +74,7 @@ typedef struct lnsfaid_code {
  * shipped values for a DecodeMethod.
  */
 typedef struct lnsfaid_cfg {
-    int32_t decode_method;     /* Profile.txt DecodeMethod: 1, 2, 3, 4 or 5 (README.md:13) */
+    int32_t decode_method;     /* Profile.txt DecodeMethod 0..5 (README.md:13; 0 = NMS, CLDPC::Decode) */
     int32_t max_iteration;     /* Profile.txt MaxIteration (nb_iteration)           */
     int32_t factor_1;          /* Profile.txt Factor_1 (selective offset, OMS)      */
     int32_t factor_2;          /* Profile.txt Factor_2                              */
@@ -108,7 +110,7 @@ typedef struct lnsfaid_ctx lnsfaid_ctx;
  * entries.  Returns LNSFAID_OK. */
 int lnsfaid_code_50gpon(lnsfaid_code* code, uint16_t* pos_vn, int32_t* deg3, int32_t* deg_rows3);
 
-/* Fill `cfg` with the reference's shipped constants for DecodeMethod 1, 2, 3, 4 or 5. */
+/* Fill `cfg` with the reference's shipped constants for DecodeMethod 0..5. */
 int lnsfaid_cfg_default(lnsfaid_cfg* cfg, int32_t decode_method, int32_t max_iteration);
 
 /* ---- decoder context --------------------------------------------------------- */

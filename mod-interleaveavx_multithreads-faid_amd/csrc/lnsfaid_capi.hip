@@ -139,19 +139,20 @@ static void build_wcols(LfDevCode* code, int W)
 static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
 {
     if (!cfg) return LNSFAID_E_INVAL;
-    if (cfg->decode_method < 1 || cfg->decode_method > 5) return LNSFAID_E_INVAL;
+    if (cfg->decode_method < 0 || cfg->decode_method > 5) return LNSFAID_E_INVAL;
     if (cfg->max_iteration < 0 || cfg->max_iteration > (1 << 20)) return LNSFAID_E_INVAL;
     if (cfg->max_bf_iter < 0 || cfg->max_bf_iter > (1 << 20)) return LNSFAID_E_INVAL;
     if (cfg->regular_col_weight < 0 || cfg->regular_col_weight > LF_MAX_COLW) return LNSFAID_E_INVAL;
     memset(out, 0, sizeof(*out));
     out->method = cfg->decode_method;
     out->max_iter = cfg->max_iteration;
-    out->factor_1 = (int8_t)cfg->factor_1; /* VECTOR_SET1: int8 lanes */
-    out->factor_2 = (int8_t)cfg->factor_2;
+    /* OMS: VECTOR_SET1 int8 lanes; NMS: VECTOR_SET2 int16 lanes (CLDPC.cpp:337, :345) */
+    out->factor_1 = cfg->decode_method == 0 ? (int16_t)cfg->factor_1 : (int8_t)cfg->factor_1;
+    out->factor_2 = cfg->decode_method == 0 ? (int16_t)cfg->factor_2 : (int8_t)cfg->factor_2;
     out->floor_err_count = cfg->floor_err_count;
     out->floor_iter_thresh = cfg->floor_iter_thresh;
     out->ef = cfg->ef_elimination;
-    out->max_bf = cfg->decode_method == 1 ? 0 : cfg->max_bf_iter; /* Decode_OMS has no BF stage */
+    out->max_bf = (cfg->decode_method == 0 || cfg->decode_method == 1) ? 0 : cfg->max_bf_iter; /* Decode / Decode_OMS have no BF stage */
     out->L0 = cfg->bf_L0; out->L1 = cfg->bf_L1; out->alpha = cfg->bf_alpha; out->delta = cfg->bf_delta;
     out->W = cfg->regular_col_weight;
     out->hard2_thr = cfg->hard2_threshold;

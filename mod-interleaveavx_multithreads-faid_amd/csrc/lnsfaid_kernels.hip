@@ -39,6 +39,8 @@
 
 /* DecodeMethods whose layered loop is Decode_OMS's: 1 (alone), 3 (+ plain bit flipping), 4 (+ DTBF) */
 #define LF_OMS(M) ((M) == 1 || (M) == 3 || (M) == 4)
+/* DecodeMethod 0 (CLDPC::Decode, normalised min-sum) shares the un-clamped V2C and the plain sign with the OMS loop */
+#define LF_MINSUM(M) ((M) == 0 || LF_OMS(M))
 
 #define SAT_POS_VAR 31 /* Constants_SSE.h:22 */
 #define SAT_NEG_VAR (-31)
@@ -261,13 +263,18 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             adr[j] = ad;
             const int eA = sEn[ad], eB = sEn[ad ^ 128u];
             const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
-            const u2 ne = pk_nonzero(IDXo ^ JJ(j));
-            const u2 mag = pk_mad(ne, DCo, C1o);
+            u2 mag;
+            if (METHOD == 0) { /* stored per edge: was |t| == min1 (ties matter: cste_1 and cste_2 use different factors) */
+                const uint32_t imb = ((j < 16 ? cur.w : cur.y) >> (j < 16 ? j : j - 16 + 8)) & 0x00010001u;
+                mag = pk_mad(US(imb), C1o - C2o, C2o);
+            } else {
+                mag = pk_mad(pk_nonzero(IDXo ^ JJ(j)), DCo, C1o);
+            }
             /* Lmn = neg ? -mag : mag, so En - Lmn = En + q * mag with q = 2 * neg - 1 */
             const uint32_t nb = ((j < 16 ? XL : XH) >> (j & 15)) & 0x00010001u;
             s2 t = pk_max(pk_mad_i(pk_2b_minus_1(nb), S(U(mag)), E), (s2)(SAT_NEG_VAR)); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
             s2 yy;
-            if (LF_OMS(METHOD)) {
+            if (LF_MINSUM(METHOD)) {
                 yy = pk_mad_i(t, S(c64), S(0x00200020u)); /* 64 t + 32: sign(yy) = (t < 0), CDecoder_OMS.cpp:372 */
             } else {
                 t = pk_min(t, (s2)(SAT_POS_VAR)); /* CDecoder_FAID.cpp:672 */
@@ -275,9 +282,10 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             }
             y[j] = U(yy);
             sx ^= U(yy);
-            const s2 a = pk_min(pk_max(t, (s2)(0) - t), (s2)(SAT_POS_MSG)); /* |t| >= 8 maps through column 7 */
+            s2 a = pk_max(t, (s2)(0) - t);
+            if (METHOD != 0) a = pk_min(a, (s2)(SAT_POS_MSG)); /* |t| >= 8 maps through column 7; NMS keeps |t| (CLDPC.cpp:329) */
             uint32_t m;
-            if (LF_OMS(METHOD)) {
+            if (LF_MINSUM(METHOD)) {
                 m = U(a); /* CDecoder_OMS.cpp:374 */
             } else {
                 if (!UNIW) {
@@ -301,7 +309,15 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     const u2 min1 = k1 >> (u2)(8), min2 = k2 >> (u2)(8);
     const uint32_t JM = U(k1) & 0x00ff00ffu;
     u2 C1n, C2n;
-    if (LF_OMS(METHOD)) {
+    if (METHOD == 0) {
+        /* cste_2 = min(((min1 * Factor_1) & 0xffff) >> 5, 7), cste_1 likewise from min2 and Factor_2 (CLDPC.cpp:337-352;
+         * the signed-saturating pack never triggers below the limit of 7) */
+        const uint32_t g1 = (uint32_t)(uint16_t)(int16_t)f1, g2 = (uint32_t)(uint16_t)(int16_t)f2;
+        const uint32_t a2 = imin((int)(((min1.x * g1) & 0xffffu) >> 5), SAT_POS_MSG), b2 = imin((int)(((min1.y * g1) & 0xffffu) >> 5), SAT_POS_MSG);
+        const uint32_t a1 = imin((int)(((min2.x * g2) & 0xffffu) >> 5), SAT_POS_MSG), b1 = imin((int)(((min2.y * g2) & 0xffffu) >> 5), SAT_POS_MSG);
+        C1n = US(a1 | (b1 << 16));
+        C2n = US(a2 | (b2 << 16));
+    } else if (LF_OMS(METHOD)) {
         const bool FA = prA && lme, FB = prB && lme;
         const int a1 = imin(oms_offset(min2.x, window, FA, f1, f2), SAT_POS_MSG); /* cste_1, CDecoder_OMS.cpp:431 */
         const int a2 = imin(oms_offset(min1.x, window, FA, f1, f2), SAT_POS_MSG); /* cste_2 */
@@ -319,13 +335,20 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     const uint32_t Fn = U(S(sx) >> (s2)(15)) ^ (((DEG > 0 ? DEG : deg) & 1) ? 0xffffffffu : 0u);
     const uint32_t Fn01 = Fn & 0x00010001u;
 
-    uint32_t nXL = 0, nXH = 0;
+    uint32_t nXL = 0, nXH = 0, nIL = 0, nIH = 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         if (DEG > 0 || j < deg) {
             const s2 yy = S(y[j]);
-            const s2 t = (LF_OMS(METHOD)) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
-            const u2 ne = pk_nonzero(JM ^ JJ(j));
+            const s2 t = (LF_MINSUM(METHOD)) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
+            u2 ne;
+            if (METHOD == 0) { /* by value: every edge with |t| == min1 takes cste_1 (CLDPC.cpp:371-375) */
+                ne = pk_nonzero(U(pk_max(t, (s2)(0) - t)) ^ U(min1));
+                const uint32_t im = U(ne) ^ 0x00010001u;
+                if (j < 16) nIL |= im << j; else nIH |= im << (j - 16);
+            } else {
+                ne = pk_nonzero(JM ^ JJ(j));
+            }
             const u2 mag = pk_mad(ne, DCn, C1n);
             const uint32_t sb = U(US(U(yy)) >> (u2)(15)); /* raw sign s_j per half */
             /* new Lmn = (s_j ^ F) ? -mag : mag, so t + Lmn = t + q * mag with q = 1 - 2 * (s_j ^ F) */
@@ -336,6 +359,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             sEn[ad ^ 128u] = (int8_t)en.y;
         }
     }
+    if (METHOD == 0) return make_uint4(nXL, nXH | (nIH << 8), (U(C1n) << 5) | (U(C2n) << 8) | (Fn & 0x80008000u), nIL);
     return make_uint4(nXL, nXH, JM | (U(C1n) << 5) | (U(C2n) << 8) | (Fn & 0x80008000u), 0u);
 }
 
@@ -647,7 +671,10 @@ __global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
                 __syncthreads();
             }
             uint32_t pA = 0, pB = 0;
-            if (!in_bf) {
+            if (METHOD == 0) { /* CLDPC::Decode has no syndrome stage and no early stop */
+                main_step<METHOD, UNIW>(c, f, sEn, g_rows, tid, prog, 0u, 0u, false);
+                prog++;
+            } else if (!in_bf) {
                 bool lme = false;
                 /* l_checksum_ and the unsatisfied count are consumed only inside the error-floor window
                  * (nombre_iterations <= floor_iter_thresh: OMS selective offset CDecoder_OMS.cpp:388, 2B1C tables
@@ -777,6 +804,7 @@ extern "C" hipError_t lf_launch_decode(int method, int uniform_w, const LfKernel
                                        hipStream_t stream)
 {
     switch (method) {
+    case 0: return launch_method<0>(true, args, lds_bytes, stream); /* normalised min-sum */
     case 1: return launch_method<1>(true, args, lds_bytes, stream); /* OMS has no look-up table */
     case 2: return launch_method<2>(uniform_w != 0, args, lds_bytes, stream);
     case 3: return launch_method<3>(true, args, lds_bytes, stream); /* OMS arithmetic + plain bit flipping */

@@ -97,6 +97,10 @@ int lnsfaid_cfg_default(lnsfaid_cfg* cfg, int32_t decode_method, int32_t max_ite
     cfg->bf_vote_cap = 5;        /* CDecoder_OMSBF.cpp:3332 */
     for (int it = 0; it < 6; ++it) fill_map(cfg->v2c_map_ef[it], ef);
     switch (decode_method) {
+    case 0: /* Decode: normalised min-sum, Factor_1 / Factor_2 are numerators over 32 (CLDPC.cpp:337-352) */
+        cfg->max_bf_iter = 0;
+        for (int it = 0; it < 6; ++it) fill_map(cfg->v2c_map[it], ident);
+        break;
     case 1: /* Decode_OMS */
         cfg->floor_err_count = 100;  /* CDecoder_OMS.cpp:28 */
         cfg->floor_iter_thresh = 4;  /* CDecoder_OMS.cpp:29 */

@@ -121,6 +121,7 @@ uint64_t CLDPC::DrawsPerGroup(int mod_type)
     return (uint64_t)32 * (uint64_t)m_N / (uint64_t)mod_type * 4u; /* 2 normals per symbol, 2 uniforms per normal */
 }
 
+void CLDPC::Decode() { decode_with(0); }
 void CLDPC::Decode_OMS() { decode_with(1); }
 void CLDPC::Decode_FAID() { decode_with(2); }
 void CLDPC::Decode_FAID_2B1C() { decode_with(5); }

@@ -44,6 +44,7 @@ public:
     void FakeEncoder(const int* CodeWord_sym = nullptr); /* nullptr = the shipped all-zero CodeWord_sym */
     void float2LimitChar_4bit(int8_t* output, const float* input, float scale, size_t length);
 
+    void Decode();           /* DecodeMethod 0 and the switch default: normalised min-sum (reference CLDPC.cpp:214) */
     void Decode_OMS();       /* DecodeMethod 1 */
     void Decode_FAID();      /* DecodeMethod 2 */
     void Decode_FAID_2B1C(); /* DecodeMethod 5 */

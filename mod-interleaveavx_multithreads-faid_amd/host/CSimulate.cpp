@@ -54,7 +54,8 @@ void CSimulate::Configure(float Eb_N0, int _decode_method)
     snr = Eb_N0; /* reference CSimulate.cpp:67-74 */
     if (ModulationType == 1) sigma = (float)(1.0 / sqrt(2.0 * ldpc->m_Rate * ModulationType * pow(10.0, 0.1 * snr)));
     else sigma = (float)(1.0 / sqrt(ldpc->m_Rate * ModulationType * pow(10.0, 0.1 * snr)));
-    decode_method = _decode_method;
+    /* the reference's switch sends every value outside 1..5 to Decode() (CSimulate.cpp:161-163) */
+    decode_method = (_decode_method >= 1 && _decode_method <= 5) ? _decode_method : 0;
     TestFrame = ErrorFrame = ErrorBits = LT3ErrBitFrame = 0;
 }
 
@@ -139,14 +140,13 @@ void CSimulate::Run()
         }
         const auto t0 = std::chrono::steady_clock::now();
         switch (decode_method) { /* reference CSimulate.cpp:136-164 */
+        case 0: ldpc->Decode(); break;
         case 1: ldpc->Decode_OMS(); break;
         case 2: ldpc->Decode_FAID(); break;
         case 3: (void)ldpc->Decode_OMSBF(); break;
         case 4: (void)ldpc->Decode_OMS_DTBF(); break;
         case 5: ldpc->Decode_FAID_2B1C(); break;
-        default:
-            fprintf(stderr, "DecodeMethod %d is not implemented on this path (1, 2, 3, 4, 5 are)\n", decode_method);
-            exit(EXIT_FAILURE);
+        default: ldpc->Decode(); break; /* as the reference: any other value runs NMS */
         }
         decode_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (!device_frontend)

@@ -40,7 +40,7 @@ static inline V sel(V mask, V a, V b) { return _mm256_blendv_epi8(b, a, mask); }
 int lnsfaid_cpu_create(lnsfaid_cpu** out, const lnsfaid_code* code, const lnsfaid_cfg* cfg)
 {
     if (!out || !code || !cfg || !code->pos_vn) return LNSFAID_E_INVAL;
-    if (cfg->decode_method < 1 || cfg->decode_method > 5) return LNSFAID_E_INVAL;
+    if (cfg->decode_method < 0 || cfg->decode_method > 5) return LNSFAID_E_INVAL;
     lnsfaid_cpu* o = (lnsfaid_cpu*)calloc(1, sizeof(*o));
     if (!o) return LNSFAID_E_NOMEM;
     o->code = *code;
@@ -110,12 +110,22 @@ static V oms_off(V x, int window, V F, V f1, V f2, V one)
     return x;
 }
 
+/* (zero-extended v * factor) >> 5 in 16-bit lanes, signed-saturating pack, limit to 7 (CLDPC.cpp:337-352) */
+static V nms_scale(V v, int factor, V v7)
+{
+    const V f = _mm256_set1_epi16((short)factor), z = _mm256_setzero_si256();
+    V lo = _mm256_srli_epi16(_mm256_mullo_epi16(_mm256_unpacklo_epi8(v, z), f), 5);
+    V hi = _mm256_srli_epi16(_mm256_mullo_epi16(_mm256_unpackhi_epi8(v, z), f), 5);
+    return _mm256_min_epi8(_mm256_packs_epi16(lo, hi), v7);
+}
+
 static void decode_group(lnsfaid_cpu* o, const int8_t* fix, int8_t* out, lnsfaid_group_stats* st)
 {
     const lnsfaid_cfg* c = &o->cfg;
     const int N = o->code.n_var, M = o->code.n_check, K = N - M, E = o->code.n_edges;
     const int oms = c->decode_method == 1 || c->decode_method == 3 || c->decode_method == 4, ef = c->ef_elimination >= 1;
-    const int with_bf = c->decode_method != 1;
+    const int with_bf = c->decode_method != 1 && c->decode_method != 0;
+    const int nms = c->decode_method == 0;
     const V zero = _mm256_setzero_si256(), one = set1(1), ones = set1(-1);
     const V vmin = set1(-31), vmax = set1(31), v7 = set1(7), sbit = set1((char)0x80);
     const V f1 = set1(c->factor_1), f2 = set1(c->factor_2);
@@ -134,7 +144,34 @@ static void decode_group(lnsfaid_cpu* o, const int8_t* fix, int8_t* out, lnsfaid
     }
 
     int executed = 0;
-    for (int rem = c->max_iteration - 1; rem >= 0; --rem) {
+    for (int itn = 0; nms && itn < c->max_iteration; ++itn) { /* CLDPC::Decode: no syndrome stage, fixed iterations */
+        size_t e = 0;
+        for (int r = 0; r < M; ++r) {
+            const int deg = o->row_deg[r];
+            V tv[MAXDEG];
+            V sign = zero, min1 = vmax, min2 = vmax;
+            for (int j = 0; j < deg; ++j) {
+                const V t = _mm256_max_epi8(_mm256_subs_epi8(o->En[o->pos[e + j]], o->Lmn[e + j]), vmin);
+                const V a = _mm256_abs_epi8(t);
+                tv[j] = t;
+                sign = _mm256_xor_si256(sign, _mm256_and_si256(t, sbit));
+                min2 = _mm256_min_epi8(min2, _mm256_max_epi8(min1, a));
+                min1 = _mm256_min_epi8(min1, a);
+            }
+            const V c2 = nms_scale(min1, c->factor_1, v7), c1 = nms_scale(min2, c->factor_2, v7);
+            if (deg & 1) sign = _mm256_xor_si256(sign, sbit);
+            for (int j = 0; j < deg; ++j) {
+                const V mag = sel(eq(_mm256_abs_epi8(tv[j]), min1), c1, c2);
+                const V neg = _mm256_xor_si256(sign, _mm256_and_si256(tv[j], sbit));
+                const V l2 = sel(neg, _mm256_sub_epi8(zero, mag), mag);
+                o->Lmn[e + j] = l2;
+                o->En[o->pos[e + j]] = _mm256_min_epi8(_mm256_max_epi8(_mm256_adds_epi8(tv[j], l2), vmin), vmax);
+            }
+            e += (size_t)deg;
+        }
+        executed++;
+    }
+    for (int rem = c->max_iteration - 1; rem >= 0 && !nms; --rem) {
         /* syndrome stage */
         V esum = zero;
         const uint16_t* p = o->pos;

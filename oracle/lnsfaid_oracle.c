@@ -8,6 +8,7 @@
  * What it restates (plain C, one function per reference stage, group of 32 lanes in lock-step,
  * every reference SIMD operation rewritten as a 32-lane scalar loop with the same int8
  * saturation semantics):
+ *   - Decode            reference CLDPC.cpp:214-2302            (DecodeMethod 0 / default: normalised min-sum)
  *   - Decode_OMS        reference CDecoder_OMS.cpp:13-2998      (DecodeMethod 1)
  *   - Decode_FAID       reference CDecoder_FAID.cpp:176-7135    (DecodeMethod 2, FAID + DTBF)
  *   - Decode_FAID_2B1C  reference CDecoder_FAID_2B1C.cpp:96-6866 (DecodeMethod 5)
@@ -100,7 +101,7 @@ struct lnsfaid_oracle {
 int lnsfaid_oracle_create(lnsfaid_oracle** out, const lnsfaid_code* code, const lnsfaid_cfg* cfg)
 {
     if (!out || !code || !cfg || !code->pos_vn) return LNSFAID_E_INVAL;
-    if (cfg->decode_method < 1 || cfg->decode_method > 5) return LNSFAID_E_INVAL;
+    if (cfg->decode_method < 0 || cfg->decode_method > 5) return LNSFAID_E_INVAL;
     lnsfaid_oracle* o = (lnsfaid_oracle*)calloc(1, sizeof(*o));
     if (!o) return LNSFAID_E_NOMEM;
     o->code = *code;
@@ -310,6 +311,54 @@ static void layered_iteration(lnsfaid_oracle* o, int nombre_iterations /* remain
     }
 }
 
+/* Normalised min-sum of CLDPC::Decode (CLDPC.cpp:337-352): (zero-extended min * factor) >> 5 in 16-bit lanes
+ * (VECTOR_UNPACK_*, VECTOR_MUL = _mm256_mullo_epi16, VECTOR_DIV32 = _mm256_srli_epi16(.., 5)), packed back with
+ * signed saturation (VECTOR_PACK = _mm256_packs_epi16), then limited to the message range. */
+static v32 nms_scale(v32 m, int factor, v32 max_msg)
+{
+    v32 r;
+    for (int l = 0; l < L; ++l) {
+        const uint16_t p = (uint16_t)((uint16_t)(uint8_t)m.b[l] * (uint16_t)(int16_t)factor);
+        const int16_t q = (int16_t)(p >> 5);
+        r.b[l] = (int8_t)(q > 127 ? 127 : (q < -128 ? -128 : q));
+    }
+    return v_min(r, max_msg);
+}
+
+/* One layered iteration of CLDPC::Decode (DecodeMethod 0, CLDPC.cpp:287-2283): no syndrome stage, no early stop. */
+static void nms_iteration(lnsfaid_oracle* o)
+{
+    const lnsfaid_cfg* c = &o->cfg;
+    const v32 min_var = v_set1(-31), max_var = v_set1(31), max_msg = v_set1(7), msign8 = v_set1((int8_t)0x80);
+    size_t e = 0;
+    for (int r = 0; r < o->code.n_check; ++r) {
+        const int deg = o->row_deg[r];
+        v32 tab_vContr[MAX_DEG];
+        v32 sign = v_set1(0), min1 = v_set1(31), min2 = min1;
+        for (int j = 0; j < deg; ++j) {
+            v32 vContr = v_max(v_subs(o->var_nodes[o->pos_vn[e + j]], o->var_msgs[e + j]), min_var);
+            sign = v_xor(sign, v_and(vContr, msign8));
+            v32 vAbs = v_abs(vContr);
+            tab_vContr[j] = vContr;
+            v32 vTemp = min1;
+            min1 = v_min(vAbs, min1);
+            min2 = v_min(min2, v_max(vTemp, vAbs));
+        }
+        const v32 cste_2 = nms_scale(min1, c->factor_1, max_msg);
+        const v32 cste_1 = nms_scale(min2, c->factor_2, max_msg);
+        sign = v_xor(sign, v_set1((int8_t)((deg & 1) ? 0xC0 : 0x40)));
+        for (int j = 0; j < deg; ++j) {
+            v32 vContr = tab_vContr[j];
+            m32 z = m_eq(v_abs(vContr), min1);
+            v32 vRes = v_mov_mask(cste_2, z, cste_1);
+            v32 v2St = v_sign(vRes, v_xor(sign, v_and(vContr, msign8)));
+            o->var_msgs[e + j] = v2St;
+            o->var_nodes[o->pos_vn[e + j]] = v_min(v_max(v_adds(vContr, v2St), min_var), max_var);
+        }
+        e += (size_t)deg;
+    }
+}
+
 /* DTBF (CDecoder_FAID.cpp:6411-7093) and 2B1C (CDecoder_FAID_2B1C.cpp:6124-6824) post-processors.
  * Returns the number of BF iterations that reached the flip step. */
 static int bit_flipping(lnsfaid_oracle* o)
@@ -436,6 +485,10 @@ static void decode_group(lnsfaid_oracle* o, const int8_t* fixInput, int8_t* deco
 
     int executed = 0;
     int nombre_iterations = c->max_iteration;
+    if (c->decode_method == 0) { /* CLDPC::Decode: fixed number of iterations */
+        while (nombre_iterations--) { nms_iteration(o); executed++; }
+        nombre_iterations = 0;
+    }
     while (nombre_iterations--) {
         v32 error_sum = syndrome_stage(o, oms);
         m32 l_m_error_sum;
@@ -451,7 +504,7 @@ static void decode_group(lnsfaid_oracle* o, const int8_t* fixInput, int8_t* deco
     }
     int bf = 0;
     if (c->decode_method == 3) bf = bit_flipping_plain(o);
-    else if (c->decode_method != 1) bf = bit_flipping(o); /* Decode_OMS alone has no bit-flipping stage */
+    else if (c->decode_method != 1 && c->decode_method != 0) bf = bit_flipping(o); /* Decode / Decode_OMS have no bit-flipping stage */
     /* uchar_itranspose_avx with LOAD_AND_DECIDE (CTool.cpp:291-575): out[l*N+v] = En[v][l] > 0 */
     const int N = o->code.n_var;
     for (int v = 0; v < N; ++v)

@@ -33,6 +33,21 @@ def test_decode_matches_oracle(abi, code50, method, eb_n0):
     _parity(abi, code50, method, 10, eb_n0, 4)
 
 
+@pytest.mark.parametrize("f1,f2,eb_n0,max_iter", [(24, 24, 3.6, 10), (24, 28, 3.0, 6), (1, 6, 3.6, 3), (20, 30, 4.2, 10), (3, 40, 3.6, 5),
+                                                  (200, 2000, 3.6, 4), (24, 24, 3.6, 1), (24, 24, 3.6, 0)])
+def test_nms_matches_oracle(abi, code50, f1, f2, eb_n0, max_iter):
+    """DecodeMethod 0 (CLDPC::Decode, reference CLDPC.cpp:214): by-value first-minimum masks, numerators over 32."""
+    cfg = abi.default_cfg(0, max_iter)
+    cfg.factor_1, cfg.factor_2 = f1, f2
+    fix = oa.ReferenceChannel(code50, 149, 13.0).groups(eb_n0, 3)
+    ref, ref_stats = oa.Oracle(code50, cfg).decode(fix, 3)
+    dec = abi.Decoder(code50, cfg, device=0, max_groups=3)
+    out, stats = dec.decode(fix, 3)
+    dec.close()
+    assert np.array_equal(out, ref)
+    assert np.array_equal(stats, ref_stats) and stats.tolist() == [[max_iter, 0]] * 3
+
+
 @pytest.mark.parametrize("method,max_iter", [(2, 6), (2, 1), (2, 0), (1, 3), (5, 7), (1, 0), (4, 5), (4, 0), (3, 4), (3, 0)])
 def test_iteration_caps(abi, code50, method, max_iter):
     _parity(abi, code50, method, max_iter, 3.6, 2, seed=103)

@@ -103,6 +103,28 @@ def test_avx2_port_equals_oracle(abi, code50, method, max_iter, eb_n0):
     assert np.array_equal(out, ref) and np.array_equal(st, rst)
 
 
+@pytest.mark.parametrize("f1,f2,eb_n0,max_iter", [(24, 24, 3.6, 10), (24, 28, 3.8, 6), (1, 6, 3.6, 3), (20, 30, 4.2, 10), (200, 2000, 3.6, 4)])
+def test_nms_avx2_port_equals_oracle(abi, code50, f1, f2, eb_n0, max_iter):
+    """DecodeMethod 0 (CLDPC::Decode): Factor_1 / Factor_2 are numerators over 32 in 16-bit lanes; every group runs all
+    iterations.  The last case drives the 16-bit product into its wrap-around."""
+    cfg = abi.default_cfg(0, max_iter)
+    cfg.factor_1, cfg.factor_2 = f1, f2
+    fix = oa.ReferenceChannel(code50, 137, 13.0).groups(eb_n0, 3)
+    ref, rst = oa.decode_mt(code50, cfg, fix, 3)
+    out, st = oa.Oracle(code50, cfg, "avx2").decode(fix, 3)
+    assert np.array_equal(out, ref) and np.array_equal(st, rst)
+    assert rst.tolist() == [[max_iter, 0]] * 3
+
+
+def test_nms_decodes_with_sensible_factors(abi, code50):
+    """Sanity of the restated NMS: 0.75-normalised min-sum (24/32) repairs nearly every frame at 3.8 dB."""
+    fix = oa.ReferenceChannel(code50, 139, 13.0).groups(3.8, 3)
+    cfg = abi.default_cfg(0, 10)
+    cfg.factor_1, cfg.factor_2 = 24, 24
+    out, _ = oa.decode_mt(code50, cfg, fix, 3)
+    assert oa.Oracle(code50, cfg).count_errors(out, None, 3)[1] <= 2
+
+
 def test_avx2_port_with_nondefault_constants(abi, code50):
     cfg = abi.default_cfg(1, 10)
     cfg.factor_1, cfg.factor_2 = 2, 5

@@ -70,8 +70,10 @@ def test_default_configurations_match_the_reference_constants(abi, lib):
     assert (c.floor_err_count, c.floor_iter_thresh, c.max_bf_iter, c.bf_vote_cap) == (100, 4, 50, 5)
     c = abi.default_cfg(4, 10, lib)  # CDecoder_OMS_DTBF.cpp:6-9, :33-35
     assert (c.floor_err_count, c.floor_iter_thresh, c.max_bf_iter, c.bf_L0, c.bf_L1, c.bf_alpha, c.bf_delta) == (100, 4, 50, 0, 50, 1, 1)
+    c = abi.default_cfg(0, 7, lib)  # CLDPC::Decode: no early stop, no bit flipping
+    assert (c.decode_method, c.max_iteration, c.max_bf_iter, c.factor_1, c.factor_2) == (0, 7, 0, 1, 6)
     bad = abi.Cfg()
-    assert lib.lnsfaid_cfg_default(C.byref(bad), 0, 10) != 0  # DecodeMethod 0 (NMS) is not on this path
+    assert lib.lnsfaid_cfg_default(C.byref(bad), 6, 10) != 0 and lib.lnsfaid_cfg_default(C.byref(bad), -1, 10) != 0
 
 
 def test_library_exports_every_symbol_of_the_header(abi, lib):
