@@ -98,6 +98,20 @@ __device__ __forceinline__ s2 pk_1_minus_2b(uint32_t b)
     return S(r);
 }
 
+/* En lives at LDS byte offset 0 of the workgroup (the decode kernel has no static LDS; checked at kernel entry), so
+ * a byte offset IS the ds_read / ds_write address: no base add per access. */
+typedef __attribute__((address_space(3))) int8_t lds_i8;
+__device__ __forceinline__ int en_ld(uint32_t off) { return *(const lds_i8*)(size_t)off; }
+__device__ __forceinline__ void en_st(uint32_t off, int v) { *(lds_i8*)(size_t)off = (int8_t)v; }
+/* LDS byte offset of row A's variable node on a circulant: ((tid + shift) mod 256) inside the block column, in
+ * two instructions (the compiler otherwise re-derives the row B address from scratch) */
+__device__ __forceinline__ uint32_t vn_offset(uint32_t tid, uint32_t sb, uint32_t vff)
+{
+    uint32_t ad;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(tid + sb), "v"(vff), "s"(sb & ~255u));
+    return ad;
+}
+
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
@@ -199,9 +213,9 @@ __device__ bool layer0_dirty(CCode c, const int8_t* sEn, int tid, uint32_t vff, 
     for (int j = 0; j < LF_MAX_DEG; ++j) {
         if (j < deg) {
             const uint32_t sb = c->circ[0][j].sb;
-            const uint32_t ad = (((uint32_t)tid + sb) & vff) | (sb & ~255u);
-            accA ^= -(int)sEn[ad];
-            accB ^= -(int)sEn[ad ^ 128u];
+            const uint32_t ad = vn_offset((uint32_t)tid, sb, vff);
+            accA ^= -en_ld(ad);
+            accB ^= -en_ld(ad ^ 128u);
         }
     }
     const unsigned long long d = __ballot((accA | accB) < 0);
@@ -239,6 +253,11 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     constexpr int NJ = DEG > 0 ? DEG : LF_MAX_DEG;
     uint32_t llo = f->lut_lo[itx][0], lhi = f->lut_hi[itx][0];
     uint32_t elo = f->lut_ef_lo[itx][0], ehi = f->lut_ef_hi[itx][0];
+    if (!LF_MINSUM(METHOD) && UNIW) {
+        /* v_perm_b32 may read one SGPR: keep the high table words in VGPRs once per layer instead of one copy per edge */
+        asm volatile("v_mov_b32 %0, %1" : "=v"(lhi) : "s"(lhi));
+        if (METHOD == 5) asm volatile("v_mov_b32 %0, %1" : "=v"(ehi) : "s"(ehi));
+    }
     const uint32_t Fo = U(S(cur.z) >> (s2)(15)); /* 0 / 0xffff per half */
     const uint32_t XL = cur.x ^ Fo, XH = cur.y ^ Fo;
     const uint32_t IDXo = cur.z & 0x001f001fu;
@@ -259,9 +278,9 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
         if (DEG > 0 || j < deg) {
             /* LDS byte address of row A's variable node: (tid + shift) mod 256 inside the block column */
             const uint32_t sb = c->circ[br][j].sb;
-            const uint32_t ad = (((uint32_t)tid + sb) & vff) | (sb & ~255u);
+            const uint32_t ad = vn_offset((uint32_t)tid, sb, vff);
             adr[j] = ad;
-            const int eA = sEn[ad], eB = sEn[ad ^ 128u];
+            const int eA = en_ld(ad), eB = en_ld(ad ^ 128u);
             const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
             u2 mag;
             if (METHOD == 0) { /* stored per edge: was |t| == min1 (ties matter: cste_1 and cste_2 use different factors) */
@@ -355,8 +374,8 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             const s2 en = pk_min(pk_max(pk_mad_i(pk_1_minus_2b(sb ^ Fn01), S(U(mag)), t), (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
             if (j < 16) nXL |= sb << j; else nXH |= sb << (j - 16);
             const uint32_t ad = adr[j];
-            sEn[ad] = (int8_t)en.x;
-            sEn[ad ^ 128u] = (int8_t)en.y;
+            en_st(ad, en.x);
+            en_st(ad ^ 128u, en.y);
         }
     }
     if (METHOD == 0) return make_uint4(nXL, nXH | (nIH << 8), (U(C1n) << 5) | (U(C2n) << 8) | (Fn & 0x80008000u), nIL);
@@ -575,6 +594,11 @@ __global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
     const int cw = (int)blockIdx.x;
     const int N = c->n_var, M = c->n_check, K = c->k_info, nw = c->n_words, pw = c->p_words;
     int8_t* sEn = (int8_t*)smem;
+    {   /* en_ld / en_st address En by its LDS offset: the dynamic segment must start at 0 */
+        uint32_t en_base = (uint32_t)(size_t)(lds_i8*)sEn;
+        asm volatile("" : "+s"(en_base)); /* link-time value: keep the compiler from assuming it */
+        if (en_base != 0u) __builtin_trap();
+    }
     uint32_t* sHard0 = (uint32_t*)smem;      /* bit-flipping stage: hard_ch and hard2 overlay the dead En */
     uint32_t* sHard2 = (uint32_t*)smem + nw;
     uint32_t* sHard = (uint32_t*)(smem + lf_lds_off_hard(N));
