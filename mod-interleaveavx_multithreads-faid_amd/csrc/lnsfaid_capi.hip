@@ -99,6 +99,7 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
         out->deg[br] = deg;
         const uint16_t* row0 = code->pos_vn + e;
         for (int j = 0; j < 32; ++j) out->syn[br][j] = 0xffffffffu;
+        for (int j = 0; j < 64; ++j) out->sbtab[br][j] = 0u;
         int prev_cb = -1;
         for (int j = 0; j < deg; ++j) {
             const int cb = row0[j] / Z, sh = row0[j] % Z;
@@ -106,6 +107,7 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
             prev_cb = cb;
             out->circ[br][j].sb = (uint32_t)cb * (uint32_t)Z + (uint32_t)sh;
             out->syn[br][j] = (uint32_t)sh | ((uint32_t)cb << 8);
+            out->sbtab[br][LF_JCODE_A(j)] = out->sbtab[br][LF_JCODE_B(j)] = out->circ[br][j].sb;
             if (out->col_weight[cb] >= LF_MAX_COLW) return LNSFAID_E_CODE;
             out->colcirc[cb][out->col_weight[cb]++] = (uint32_t)br | ((uint32_t)sh << 8);
         }

@@ -19,6 +19,11 @@
 #define LF_DONE 0x40000000 /* status flag: codeword finished; low bits keep its last decision point */
 #define LF_PROG_MASK 0x0fffffff
 
+/* Edge j of a row pair inside the 16-bit min-search key: the bit index of its sign in the 64-bit pair
+ * {.y, .x} of the compressed messages (row A: low halves, row B: high halves); also its lane in sbtab. */
+#define LF_JCODE_A(j) ((j) < 16 ? (j) : (j) + 16)
+#define LF_JCODE_B(j) ((j) < 16 ? (j) + 16 : (j) + 32)
+
 struct LfCirc {
     uint32_t sb;     /* block column * 256 + circulant shift: LDS byte offset of row 0's variable node */
     uint32_t wclass; /* weight class 0..3 of the block column (V2C_map row)                            */
@@ -31,6 +36,7 @@ struct LfDevCode {
     int32_t n_wcols;                          /* block columns whose weight equals REGULAR_COL_WEIGHT           */
     int32_t deg[LF_MAX_BR];
     LfCirc circ[LF_MAX_BR][LF_MAX_DEG];
+    uint32_t sbtab[LF_MAX_BR][64];            /* lane LF_JCODE_A(j) and lane LF_JCODE_B(j): circ[br][j].sb              */
     uint32_t syn[LF_MAX_BR][32];              /* lane j: shift | block column << 8 of circulant j, ~0u beyond deg */
     int32_t col_weight[LF_MAX_BC];
     int32_t wcol[LF_MAX_BC];                  /* the n_wcols block columns of weight W                           */

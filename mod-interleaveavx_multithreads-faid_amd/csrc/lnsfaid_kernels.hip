@@ -112,6 +112,14 @@ __device__ __forceinline__ uint32_t vn_offset(uint32_t tid, uint32_t sb, uint32_
     return ad;
 }
 
+/* (a & mask) | (b & ~mask) */
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
@@ -237,36 +245,62 @@ __device__ __forceinline__ int oms_offset(int x, bool window, bool F, int f1, in
 }
 
 #define JJ(j) ((uint32_t)(j) | ((uint32_t)(j) << 16))
+/* edge j inside the min-search key: LF_JCODE_A / LF_JCODE_B per half (bit index of the edge's sign, lane of sbtab) */
+#define JC(j) ((uint32_t)LF_JCODE_A(j) | ((uint32_t)LF_JCODE_B(j) << 16))
 
-/* ---- one layered iteration (FAID / 2B1C: CDecoder_FAID.cpp:631-1527; OMS: CDecoder_OMS.cpp:334-743) -----
+/* ---- one layered iteration (FAID / 2B1C: CDecoder_FAID.cpp:631-1527; OMS: CDecoder_OMS.cpp:334-743; NMS:
+ * CLDPC.cpp:287-2283) -----------------------------------------------------------------------------------------
  * rows: this codeword's compressed messages, [nbr][128] uint4 for the row pair (tid, tid+128); 16-bit halves:
  *   .x bit j (j < 16), .y bit j-16: raw sign s_j of the V2C on edge j, low half row A, high half row B
- *   .z per half: argmin edge | c1 << 5 | c2 << 8 | F << 15, F = XOR_all(s) ^ (deg odd)
- *   Lmn(edge j) = (j == argmin ? c1 : c2), negative iff s_j ^ F */
-/* One layer for the row pair of this thread.  DEG > 0: compile-time degree (no per-edge branches, so the
- * scheduler can issue all table loads and LDS reads of the row up front and interleave the edges);
- * DEG == 0: run-time degree `deg` with a guard per edge. */
+ *   .z per half: c1 << 5 | c2 << 8 | n << 11 | F << 15, F = XOR_all(s) ^ (deg odd), n = s ^ F of the argmin edge
+ *   .w per half: LDS offset of the argmin edge's variable node
+ *   Lmn(edge j) = (j == argmin ? c1 : c2), negative iff s_j ^ F
+ * DecodeMethod 0 keeps a by-value mask instead (its two constants use different factors):
+ *   .w bit j / .y bit 8 + j - 16: |t_j| == min1, no argmin fields.
+ *
+ * Only ONE edge per row carries c1.  Both passes therefore treat every edge as if it carried c2 and the argmin edge is
+ * patched through LDS instead of selecting per edge:
+ *   before pass 1   En[argmin_old] += q (c1 - c2): (En + q (c1 - c2)) + q c2 = En + q c1, the exact V2C
+ *   after pass 1    the new argmin edge's V2C is recomputed from En (still the old value), its exact new En replaces
+ *                   the as-if value pass 2 writes (same thread, LDS operations of a wave execute in order)
+ * No other row of the layer touches these variable nodes, so the detour is invisible outside this function.
+ *
+ * DEG > 0: compile-time degree (no per-edge branches, so the scheduler can issue all table loads and LDS reads of
+ * the row up front and interleave the edges); DEG == 0: run-time degree `deg` with a guard per edge. */
 template <int METHOD, bool UNIW, int DEG>
 __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int tid, int br, int deg, int itx, bool window,
-                                            bool lme, int f1, int f2, uint4 cur, bool prA, bool prB, uint32_t vff)
+                                            bool lme, int f1, int f2, uint4 cur, bool prA, bool prB, uint32_t vff,
+                                            uint32_t sbtab, bool fresh)
 {
     constexpr int NJ = DEG > 0 ? DEG : LF_MAX_DEG;
+    constexpr bool PATCH = (METHOD != 0);
     uint32_t llo = f->lut_lo[itx][0], lhi = f->lut_hi[itx][0];
     uint32_t elo = f->lut_ef_lo[itx][0], ehi = f->lut_ef_hi[itx][0];
-    if (!LF_MINSUM(METHOD) && UNIW) {
-        /* v_perm_b32 may read one SGPR: keep the high table words in VGPRs once per layer instead of one copy per edge */
-        asm volatile("v_mov_b32 %0, %1" : "=v"(lhi) : "s"(lhi));
-        if (METHOD == 5) asm volatile("v_mov_b32 %0, %1" : "=v"(ehi) : "s"(ehi));
+    uint32_t selk = 0;
+    if (!LF_MINSUM(METHOD)) {
+        if (UNIW) {
+            /* v_perm_b32 may read one SGPR: keep the high table words in VGPRs once per layer instead of one copy per edge */
+            asm volatile("v_mov_b32 %0, %1" : "=v"(lhi) : "s"(lhi));
+            if (METHOD == 5) asm volatile("v_mov_b32 %0, %1" : "=v"(ehi) : "s"(ehi));
+        }
+        asm volatile("v_mov_b32 %0, 0x06020400" : "=v"(selk)); /* key = {m.b2, code.b2, m.b0, code.b0} */
     }
     const uint32_t Fo = U(S(cur.z) >> (s2)(15)); /* 0 / 0xffff per half */
     const uint32_t XL = cur.x ^ Fo, XH = cur.y ^ Fo;
-    const uint32_t IDXo = cur.z & 0x001f001fu;
     const u2 C1o = US((cur.z >> 5) & 0x00070007u), C2o = US((cur.z >> 8) & 0x00070007u);
-    const u2 DCo = C2o - C1o;
     uint32_t c64;
     asm volatile("v_mov_b32 %0, 0x400040" : "=v"(c64)); /* packed 64 kept in a VGPR for v_pk_mad_i16 */
     uint32_t efmask = 0; /* mask_eef per row, CDecoder_FAID.cpp:713-720 */
     if (METHOD == 5 && window && lme) efmask = (prA ? 0x0000ffffu : 0u) | (prB ? 0xffff0000u : 0u);
+
+    if (PATCH && !fresh) {
+        const uint32_t pa = cur.w & 0xffffu, pb = cur.w >> 16;
+        const int eA = en_ld(pa), eB = en_ld(pb);
+        const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
+        const s2 Ep = pk_mad_i(pk_2b_minus_1((cur.z >> 11) & 0x00010001u), S(U(C1o - C2o)), E);
+        en_st(pa, Ep.x);
+        en_st(pb, Ep.y);
+    }
 
     uint32_t y[NJ];
     uint32_t adr[NJ];
@@ -277,17 +311,14 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     for (int j = 0; j < NJ; ++j) {
         if (DEG > 0 || j < deg) {
             /* LDS byte address of row A's variable node: (tid + shift) mod 256 inside the block column */
-            const uint32_t sb = c->circ[br][j].sb;
-            const uint32_t ad = vn_offset((uint32_t)tid, sb, vff);
+            const uint32_t ad = vn_offset((uint32_t)tid, c->circ[br][j].sb, vff);
             adr[j] = ad;
             const int eA = en_ld(ad), eB = en_ld(ad ^ 128u);
             const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
-            u2 mag;
-            if (METHOD == 0) { /* stored per edge: was |t| == min1 (ties matter: cste_1 and cste_2 use different factors) */
+            u2 mag = C2o;
+            if (METHOD == 0) { /* stored per edge: was |t| == min1 */
                 const uint32_t imb = ((j < 16 ? cur.w : cur.y) >> (j < 16 ? j : j - 16 + 8)) & 0x00010001u;
                 mag = pk_mad(US(imb), C1o - C2o, C2o);
-            } else {
-                mag = pk_mad(pk_nonzero(IDXo ^ JJ(j)), DCo, C1o);
             }
             /* Lmn = neg ? -mag : mag, so En - Lmn = En + q * mag with q = 2 * neg - 1 */
             const uint32_t nb = ((j < 16 ? XL : XH) >> (j & 15)) & 0x00010001u;
@@ -303,30 +334,29 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             sx ^= U(yy);
             s2 a = pk_max(t, (s2)(0) - t);
             if (METHOD != 0) a = pk_min(a, (s2)(SAT_POS_MSG)); /* |t| >= 8 maps through column 7; NMS keeps |t| (CLDPC.cpp:329) */
-            uint32_t m;
+            u2 key;
             if (LF_MINSUM(METHOD)) {
-                m = U(a); /* CDecoder_OMS.cpp:374 */
+                key = US((U(a) << 8) | JC(j)); /* CDecoder_OMS.cpp:374 */
             } else {
                 if (!UNIW) {
                     const uint32_t wc = c->circ[br][j].wclass;
                     llo = f->lut_lo[itx][wc]; lhi = f->lut_hi[itx][wc];
                     if (METHOD == 5) { elo = f->lut_ef_lo[itx][wc]; ehi = f->lut_ef_hi[itx][wc]; }
                 }
-                const uint32_t sel = U(a) | 0x0c000c00u;
-                m = __builtin_amdgcn_perm(lhi, llo, sel);
+                /* bytes 1 and 3 of the selector are 0 and pick table entry 0: dropped again when the key is assembled */
+                uint32_t m = __builtin_amdgcn_perm(lhi, llo, U(a));
                 if (METHOD == 5) {
-                    const uint32_t me = __builtin_amdgcn_perm(ehi, elo, sel);
+                    const uint32_t me = __builtin_amdgcn_perm(ehi, elo, U(a));
                     m = (m & ~efmask) | (me & efmask);
                 }
+                key = US(__builtin_amdgcn_perm(m, JC(j), selk));
             }
-            const u2 key = US((m << 8) | JJ(j));
             k2 = pk_minu(k2, pk_maxu(k1, key)); /* VECTOR_MIN_2 with the old min1 */
             k1 = pk_minu(k1, key);
         }
     }
 
     const u2 min1 = k1 >> (u2)(8), min2 = k2 >> (u2)(8);
-    const uint32_t JM = U(k1) & 0x00ff00ffu;
     u2 C1n, C2n;
     if (METHOD == 0) {
         /* cste_2 = min(((min1 * Factor_1) & 0xffff) >> 5, 7), cste_1 likewise from min2 and Factor_2 (CLDPC.cpp:337-352;
@@ -348,11 +378,35 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
         C1n = pk_minu(min2, (u2)(SAT_POS_MSG)); /* CDecoder_FAID.cpp:865-866, offset 0 */
         C2n = pk_minu(min1, (u2)(SAT_POS_MSG));
     }
-    const u2 DCn = C2n - C1n;
     /* sign of the new message on edge j: XOR of all signs ^ (deg odd) ^ own sign
      * (the 0xC0 / 0x40 constants of CDecoder_FAID.cpp:902-906 fed to _mm256_sign_epi8) */
     const uint32_t Fn = U(S(sx) >> (s2)(15)) ^ (((DEG > 0 ? DEG : deg) & 1) ? 0xffffffffu : 0u);
     const uint32_t Fn01 = Fn & 0x00010001u;
+
+    /* ---- the new argmin edge, exactly (its En is still the old value: pass 2 has not started) ---- */
+    uint32_t pa = 0, pb = 0, nq = 0;
+    s2 en_arg = (s2)(0);
+    if (PATCH) {
+        const uint32_t ca = U(k1) & 0xffu, cb = (U(k1) >> 16) & 0xffu; /* LF_JCODE_A / _B of the argmin edges */
+        const uint32_t sba = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ca << 2), (int)sbtab);
+        const uint32_t sbb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cb << 2), (int)sbtab);
+        pa = bfi(vff, (uint32_t)tid + sba, sba);          /* as vn_offset, operands in VGPRs */
+        pb = bfi(vff, (uint32_t)tid + sbb, sbb) ^ 128u;
+        const int eA = en_ld(pa), eB = en_ld(pb);
+        const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
+        const unsigned long long X = ((unsigned long long)XH << 32) | XL;  /* bit LF_JCODE: old message negative */
+        const uint32_t nb = ((uint32_t)(X >> ca) & 1u) | (((uint32_t)(X >> cb) & 1u) << 16);
+        s2 t = pk_max(pk_mad_i(pk_2b_minus_1(nb), S(U(C2o)), E), (s2)(SAT_NEG_VAR));
+        uint32_t sj;
+        if (LF_MINSUM(METHOD)) {
+            sj = U(US(U(t)) >> (u2)(15));
+        } else {
+            t = pk_min(t, (s2)(SAT_POS_VAR));
+            sj = U(US(U(pk_mad_i(t, S(c64), E))) >> (u2)(15));
+        }
+        nq = sj ^ Fn01;
+        en_arg = pk_min(pk_max(pk_mad_i(pk_1_minus_2b(nq), S(U(C1n)), t), (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR));
+    }
 
     uint32_t nXL = 0, nXH = 0, nIL = 0, nIH = 0;
 #pragma unroll
@@ -360,15 +414,13 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
         if (DEG > 0 || j < deg) {
             const s2 yy = S(y[j]);
             const s2 t = (LF_MINSUM(METHOD)) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
-            u2 ne;
+            u2 mag = C2n;
             if (METHOD == 0) { /* by value: every edge with |t| == min1 takes cste_1 (CLDPC.cpp:371-375) */
-                ne = pk_nonzero(U(pk_max(t, (s2)(0) - t)) ^ U(min1));
+                const u2 ne = pk_nonzero(U(pk_max(t, (s2)(0) - t)) ^ U(min1));
                 const uint32_t im = U(ne) ^ 0x00010001u;
                 if (j < 16) nIL |= im << j; else nIH |= im << (j - 16);
-            } else {
-                ne = pk_nonzero(JM ^ JJ(j));
+                mag = pk_mad(ne, C2n - C1n, C1n);
             }
-            const u2 mag = pk_mad(ne, DCn, C1n);
             const uint32_t sb = U(US(U(yy)) >> (u2)(15)); /* raw sign s_j per half */
             /* new Lmn = (s_j ^ F) ? -mag : mag, so t + Lmn = t + q * mag with q = 1 - 2 * (s_j ^ F) */
             const s2 en = pk_min(pk_max(pk_mad_i(pk_1_minus_2b(sb ^ Fn01), S(U(mag)), t), (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
@@ -379,17 +431,14 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
         }
     }
     if (METHOD == 0) return make_uint4(nXL, nXH | (nIH << 8), (U(C1n) << 5) | (U(C2n) << 8) | (Fn & 0x80008000u), nIL);
-    return make_uint4(nXL, nXH, JM | (U(C1n) << 5) | (U(C2n) << 8) | (Fn & 0x80008000u), 0u);
+    en_st(pa, en_arg.x);
+    en_st(pb, en_arg.y);
+    return make_uint4(nXL, nXH, (U(C1n) << 5) | (U(C2n) << 8) | (nq << 11) | (Fn & 0x80008000u), pa | (pb << 16));
 }
 
-/* ---- one layered iteration (FAID / 2B1C: CDecoder_FAID.cpp:631-1527; OMS: CDecoder_OMS.cpp:334-743) -----
- * rows: this codeword's compressed messages, [nbr][128] uint4 for the row pair (tid, tid+128); 16-bit halves:
- *   .x bit j (j < 16), .y bit j-16: raw sign s_j of the V2C on edge j, low half row A, high half row B
- *   .z per half: argmin edge | c1 << 5 | c2 << 8 | F << 15, F = XOR_all(s) ^ (deg odd)
- *   Lmn(edge j) = (j == argmin ? c1 : c2), negative iff s_j ^ F */
 template <int METHOD, bool UNIW>
-__device__ void main_step(CCode c, CCfg f, int8_t* sEn, uint4* __restrict__ rows, int tid, int it, uint32_t pA,
-                          uint32_t pB, bool lme)
+__device__ void main_step(CCode c, CCfg f, const LfDevCode* gc, int8_t* sEn, uint4* __restrict__ rows, int tid, int it,
+                          uint32_t pA, uint32_t pB, bool lme)
 {
     const bool fresh = (it == 1); /* no iteration has run yet: every Lmn is still 0, nothing in HBM */
     const int rem = f->max_iter - it; /* nombre_iterations inside the loop body */
@@ -402,15 +451,18 @@ __device__ void main_step(CCode c, CCfg f, int8_t* sEn, uint4* __restrict__ rows
 
     uint4 cur = make_uint4(0u, 0u, 0u, 0u); /* Lmn = 0 before the first iteration (CDecoder_FAID.cpp:211-214) */
     if (!fresh) cur = rows[tid];
+    uint32_t tab = gc->sbtab[0][tid & 63]; /* lane-indexed: vector load, one layer ahead like the messages */
     for (int br = 0; br < nbr; ++br) {
         uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
         if (!fresh && br + 1 < nbr) nxt = rows[(br + 1) * LF_T + tid]; /* one layer ahead of use */
+        const uint32_t tab_cur = tab;
+        if (br + 1 < nbr) tab = gc->sbtab[br + 1][tid & 63];
         const int deg = c->deg[br];
         const bool prA = (pA >> br) & 1u, prB = (pB >> br) & 1u;
         uint4 st;
-        if (deg == 23) st = layer_step<METHOD, UNIW, 23>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff);
-        else if (deg == 22) st = layer_step<METHOD, UNIW, 22>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff);
-        else st = layer_step<METHOD, UNIW, 0>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff);
+        if (deg == 23) st = layer_step<METHOD, UNIW, 23>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff, tab_cur, fresh);
+        else if (deg == 22) st = layer_step<METHOD, UNIW, 22>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff, tab_cur, fresh);
+        else st = layer_step<METHOD, UNIW, 0>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff, tab_cur, fresh);
         if (rem > 0) rows[br * LF_T + tid] = st; /* the last layered iteration's messages are never read again */
         __syncthreads(); /* the next layer reads what this one wrote */
         cur = nxt;
@@ -696,7 +748,7 @@ __global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
             }
             uint32_t pA = 0, pB = 0;
             if (METHOD == 0) { /* CLDPC::Decode has no syndrome stage and no early stop */
-                main_step<METHOD, UNIW>(c, f, sEn, g_rows, tid, prog, 0u, 0u, false);
+                main_step<METHOD, UNIW>(c, f, a.code, sEn, g_rows, tid, prog, 0u, 0u, false);
                 prog++;
             } else if (!in_bf) {
                 bool lme = false;
@@ -711,7 +763,7 @@ __global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
                     if (LF_OMS(METHOD)) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
                     else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
                 }
-                main_step<METHOD, UNIW>(c, f, sEn, g_rows, tid, prog, pA, pB, lme);
+                main_step<METHOD, UNIW>(c, f, a.code, sEn, g_rows, tid, prog, pA, pB, lme);
                 prog++;
             } else {
                 const int unsat = syndrome(c, a.code, sHard, sP, tid, pA, pB, sRed);
