@@ -172,6 +172,9 @@ static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
                 uint32_t* le = a < 4 ? &out->lut_ef_lo[it][w] : &out->lut_ef_hi[it][w];
                 *l |= (uint32_t)(v & 0xff) << (8 * (a & 3));
                 *le |= (uint32_t)(ve & 0xff) << (8 * (a & 3));
+                /* a table that is not non-decreasing cannot be applied after the minimum search */
+                if (a > 0 && (v < cfg->v2c_map[it][w][a - 1] || (cfg->decode_method == 5 && ve < cfg->v2c_map_ef[it][w][a - 1])))
+                    out->uniform_w = 0;
             }
             if (out->lut_lo[it][w] != out->lut_lo[it][0] || out->lut_hi[it][w] != out->lut_hi[it][0]) out->uniform_w = 0;
             if (cfg->decode_method == 5

@@ -46,7 +46,8 @@ struct LfDevCode {
 struct LfDevCfg {
     int32_t method, max_iter, factor_1, factor_2, floor_err_count, floor_iter_thresh, ef, max_bf;
     int32_t L0, L1, alpha, delta, W, hard2_thr, vote_cap;
-    int32_t uniform_w; /* all four weight classes carry the same table rows (true for every shipped set)      */
+    int32_t uniform_w; /* all four weight classes carry the same table rows and every row is non-decreasing (true for
+                        * every shipped set): the table is then applied to the two minima instead of to every edge   */
     int32_t bf_fast;   /* W == 3 and alpha in {0, 1}: bit-sliced flip decision                                */
     /* V2C_map_it{1..6}_[class] as 8 bytes for v_perm_b32: lo = entries 0..3, hi = entries 4..7 */
     uint32_t lut_lo[6][4], lut_hi[6][4];

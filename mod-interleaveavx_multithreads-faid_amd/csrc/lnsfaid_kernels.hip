@@ -244,6 +244,9 @@ __device__ __forceinline__ int oms_offset(int x, bool window, bool F, int f1, in
     return x;
 }
 
+#ifndef LF_WAVES_PER_SIMD
+#define LF_WAVES_PER_SIMD 4 /* 128 VGPRs per wave; LDS allows 8 workgroups = 16 waves per CU */
+#endif
 #define JJ(j) ((uint32_t)(j) | ((uint32_t)(j) << 16))
 /* edge j inside the min-search key: LF_JCODE_A / LF_JCODE_B per half (bit index of the edge's sign, lane of sbtab) */
 #define JC(j) ((uint32_t)LF_JCODE_A(j) | ((uint32_t)LF_JCODE_B(j) << 16))
@@ -270,21 +273,19 @@ __device__ __forceinline__ int oms_offset(int x, bool window, bool F, int f1, in
 template <int METHOD, bool UNIW, int DEG>
 __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int tid, int br, int deg, int itx, bool window,
                                             bool lme, int f1, int f2, uint4 cur, bool prA, bool prB, uint32_t vff,
-                                            uint32_t sbtab, bool fresh)
+                                            uint32_t sbtab, bool fresh, const uint4* nxt_rows, uint4& nxt,
+                                            const uint32_t* nxt_tab, uint32_t& tab)
 {
     constexpr int NJ = DEG > 0 ? DEG : LF_MAX_DEG;
     constexpr bool PATCH = (METHOD != 0);
     uint32_t llo = f->lut_lo[itx][0], lhi = f->lut_hi[itx][0];
     uint32_t elo = f->lut_ef_lo[itx][0], ehi = f->lut_ef_hi[itx][0];
+    /* UNIW: one non-decreasing table for every edge of the row.  min(LUT[a]) = LUT[min a] and likewise for the second
+     * minimum, so the search runs on |t| and the table (and the clamp to 7 in front of it) is applied to the two
+     * results; which of several tied edges is called the argmin does not matter. */
+    constexpr bool LATE_LUT = !LF_MINSUM(METHOD) && UNIW;
     uint32_t selk = 0;
-    if (!LF_MINSUM(METHOD)) {
-        if (UNIW) {
-            /* v_perm_b32 may read one SGPR: keep the high table words in VGPRs once per layer instead of one copy per edge */
-            asm volatile("v_mov_b32 %0, %1" : "=v"(lhi) : "s"(lhi));
-            if (METHOD == 5) asm volatile("v_mov_b32 %0, %1" : "=v"(ehi) : "s"(ehi));
-        }
-        asm volatile("v_mov_b32 %0, 0x06020400" : "=v"(selk)); /* key = {m.b2, code.b2, m.b0, code.b0} */
-    }
+    if (!LF_MINSUM(METHOD) && !UNIW) asm volatile("v_mov_b32 %0, 0x06020400" : "=v"(selk)); /* key = {m.b2, code.b2, m.b0, code.b0} */
     const uint32_t Fo = U(S(cur.z) >> (s2)(15)); /* 0 / 0xffff per half */
     const uint32_t XL = cur.x ^ Fo, XH = cur.y ^ Fo;
     const u2 C1o = US((cur.z >> 5) & 0x00070007u), C2o = US((cur.z >> 8) & 0x00070007u);
@@ -305,7 +306,8 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     uint32_t y[NJ];
     uint32_t adr[NJ];
     uint32_t sx = 0;
-    u2 k1 = US(0x1fff1fffu), k2 = US(0x1fff1fffu);
+    /* NMS starts its minima from 31 like the reference's registers (CLDPC.cpp:296); elsewhere any value above the keys */
+    u2 k1 = US(METHOD == 0 ? 0x1fff1fffu : 0x7fff7fffu), k2 = k1;
 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -333,11 +335,11 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             y[j] = U(yy);
             sx ^= U(yy);
             s2 a = pk_max(t, (s2)(0) - t);
-            if (METHOD != 0) a = pk_min(a, (s2)(SAT_POS_MSG)); /* |t| >= 8 maps through column 7; NMS keeps |t| (CLDPC.cpp:329) */
             u2 key;
-            if (LF_MINSUM(METHOD)) {
-                key = US((U(a) << 8) | JC(j)); /* CDecoder_OMS.cpp:374 */
+            if (LF_MINSUM(METHOD) || LATE_LUT) {
+                key = US((U(a) << 8) | JC(j)); /* |t|; clamped to 7 (and mapped) after the search, CDecoder_OMS.cpp:374 */
             } else {
+                a = pk_min(a, (s2)(SAT_POS_MSG)); /* |t| >= 8 maps through column 7 */
                 if (!UNIW) {
                     const uint32_t wc = c->circ[br][j].wclass;
                     llo = f->lut_lo[itx][wc]; lhi = f->lut_hi[itx][wc];
@@ -356,7 +358,25 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
         }
     }
 
-    const u2 min1 = k1 >> (u2)(8), min2 = k2 >> (u2)(8);
+    /* the next layer's messages and argmin table are fetched from here on: after pass 1, where the register pressure
+     * peaks, and still most of a layer ahead of their use */
+    nxt = *nxt_rows;
+    tab = *nxt_tab;
+
+    u2 min1 = k1 >> (u2)(8), min2 = k2 >> (u2)(8);
+    if (METHOD != 0 && (LF_MINSUM(METHOD) || LATE_LUT)) {
+        min1 = pk_minu(min1, (u2)(SAT_POS_MSG));
+        min2 = pk_minu(min2, (u2)(SAT_POS_MSG));
+    }
+    if (LATE_LUT) {
+        uint32_t m1 = __builtin_amdgcn_perm(lhi, llo, U(min1) | 0x0c000c00u), m2 = __builtin_amdgcn_perm(lhi, llo, U(min2) | 0x0c000c00u);
+        if (METHOD == 5) {
+            m1 = (m1 & ~efmask) | (__builtin_amdgcn_perm(ehi, elo, U(min1) | 0x0c000c00u) & efmask);
+            m2 = (m2 & ~efmask) | (__builtin_amdgcn_perm(ehi, elo, U(min2) | 0x0c000c00u) & efmask);
+        }
+        min1 = US(m1);
+        min2 = US(m2);
+    }
     u2 C1n, C2n;
     if (METHOD == 0) {
         /* cste_2 = min(((min1 * Factor_1) & 0xffff) >> 5, 7), cste_1 likewise from min2 and Factor_2 (CLDPC.cpp:337-352;
@@ -425,7 +445,8 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             /* new Lmn = (s_j ^ F) ? -mag : mag, so t + Lmn = t + q * mag with q = 1 - 2 * (s_j ^ F) */
             const s2 en = pk_min(pk_max(pk_mad_i(pk_1_minus_2b(sb ^ Fn01), S(U(mag)), t), (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
             if (j < 16) nXL |= sb << j; else nXH |= sb << (j - 16);
-            const uint32_t ad = adr[j];
+            uint32_t ad = adr[j];
+            asm("" : "+v"(ad)); /* row B's address is recomputed here rather than kept in a register since pass 1 */
             en_st(ad, en.x);
             en_st(ad ^ 128u, en.y);
         }
@@ -453,19 +474,22 @@ __device__ void main_step(CCode c, CCfg f, const LfDevCode* gc, int8_t* sEn, uin
     if (!fresh) cur = rows[tid];
     uint32_t tab = gc->sbtab[0][tid & 63]; /* lane-indexed: vector load, one layer ahead like the messages */
     for (int br = 0; br < nbr; ++br) {
-        uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
-        if (!fresh && br + 1 < nbr) nxt = rows[(br + 1) * LF_T + tid]; /* one layer ahead of use */
+        /* always a valid address (the last layer re-reads layer 0, the first iteration reads what it is about to
+         * overwrite): the loads stay unconditional inside the layer's single basic block */
+        const int brn = br + 1 < nbr ? br + 1 : 0;
+        uint4 nxt;
+        const uint4* nxt_rows = rows + brn * LF_T + tid;
+        const uint32_t* nxt_tab = &gc->sbtab[brn][tid & 63];
         const uint32_t tab_cur = tab;
-        if (br + 1 < nbr) tab = gc->sbtab[br + 1][tid & 63];
         const int deg = c->deg[br];
         const bool prA = (pA >> br) & 1u, prB = (pB >> br) & 1u;
         uint4 st;
-        if (deg == 23) st = layer_step<METHOD, UNIW, 23>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff, tab_cur, fresh);
-        else if (deg == 22) st = layer_step<METHOD, UNIW, 22>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff, tab_cur, fresh);
-        else st = layer_step<METHOD, UNIW, 0>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff, tab_cur, fresh);
+        if (deg == 23) st = layer_step<METHOD, UNIW, 23>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff, tab_cur, fresh, nxt_rows, nxt, nxt_tab, tab);
+        else if (deg == 22) st = layer_step<METHOD, UNIW, 22>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff, tab_cur, fresh, nxt_rows, nxt, nxt_tab, tab);
+        else st = layer_step<METHOD, UNIW, 0>(c, f, sEn, tid, br, deg, itx, window, lme, f1, f2, cur, prA, prB, vff, tab_cur, fresh, nxt_rows, nxt, nxt_tab, tab);
         if (rem > 0) rows[br * LF_T + tid] = st; /* the last layered iteration's messages are never read again */
         __syncthreads(); /* the next layer reads what this one wrote */
-        cur = nxt;
+        if (!fresh) cur = nxt;
     }
 }
 
@@ -637,7 +661,7 @@ __device__ void bf_step_plain(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sH
 
 /* ---- the decode kernel: one workgroup per codeword ---------------------------------------------------- */
 template <int METHOD, bool UNIW>
-__global__ __launch_bounds__(LF_T, 4) void lnsfaid_decode_kernel(LfKernelArgs a)
+__global__ __launch_bounds__(LF_T, LF_WAVES_PER_SIMD) void lnsfaid_decode_kernel(LfKernelArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     CCode c = (CCode)a.code;

@@ -18,6 +18,17 @@
     }
 #define L8(op, tail) op " %0, %0, " tail "\n" op " %1, %1, " tail "\n" op " %2, %2, " tail "\n" op " %3, %3, " tail "\n" \
                      op " %4, %4, " tail "\n" op " %5, %5, " tail "\n" op " %6, %6, " tail "\n" op " %7, %7, " tail "\n"
+#define L8S(op, src0) op " %0, " src0 ", %0\n" op " %1, " src0 ", %1\n" op " %2, " src0 ", %2\n" op " %3, " src0 ", %3\n" \
+                      op " %4, " src0 ", %4\n" op " %5, " src0 ", %5\n" op " %6, " src0 ", %6\n" op " %7, " src0 ", %7\n"
+// is the cost the opcode class or the encoding size?  4-byte VOP2, VOP2 + 32-bit literal (8 bytes), VOP2 forced to the
+// 8-byte VOP3 encoding, VOP2 with an inline constant / an SGPR (4 bytes)
+DEF_KERNEL(k_and_lit, L8S("v_and_b32", "0x10001"))
+DEF_KERNEL(k_and_inl, L8S("v_and_b32", "15"))
+DEF_KERNEL(k_and_sgpr, L8S("v_and_b32", "s2"))
+DEF_KERNEL(k_xor_lit128, L8S("v_xor_b32", "0x80"))
+DEF_KERNEL(k_add_e64, L8("v_add_u32_e64", "%8"))
+DEF_KERNEL(k_lshr_inl, L8S("v_lshrrev_b32", "3"))
+DEF_KERNEL(k_pk_min_inl, L8("v_pk_min_i16", "31 op_sel_hi:[1,0]"))
 DEF_KERNEL(k_add_u32, L8("v_add_u32", "%8"))
 DEF_KERNEL(k_xor, L8("v_xor_b32", "%8"))
 DEF_KERNEL(k_pk_add_u16, L8("v_pk_add_u16", "%8"))
@@ -87,6 +98,9 @@ int main() {
     uint32_t* d; hipMalloc(&d, 4096 * 256 * 4);
     const int B = 4096, T = 256; // 16 waves/CU x 4 rounds
     run(k_add_u32, "v_add_u32", d, B, T, ghz, 8); run(k_xor, "v_xor_b32", d, B, T, ghz, 8);
+    run(k_and_lit, "v_and lit32", d, B, T, ghz, 8); run(k_and_inl, "v_and inline", d, B, T, ghz, 8); run(k_and_sgpr, "v_and sgpr", d, B, T, ghz, 8);
+    run(k_xor_lit128, "v_xor lit 0x80", d, B, T, ghz, 8); run(k_add_e64, "v_add_u32_e64", d, B, T, ghz, 8); run(k_lshr_inl, "v_lshrrev inl", d, B, T, ghz, 8);
+    run(k_pk_min_inl, "pk_min inline", d, B, T, ghz, 8);
     run(k_pk_add_u16, "v_pk_add_u16", d, B, T, ghz, 8); run(k_pk_sub_i16, "v_pk_sub_i16", d, B, T, ghz, 8);
     run(k_pk_min_i16, "v_pk_min_i16", d, B, T, ghz, 8); run(k_pk_max_u16, "v_pk_max_u16", d, B, T, ghz, 8);
     run(k_pk_lshl, "v_pk_lshlrev_b16", d, B, T, ghz, 8); run(k_pk_ashr, "v_pk_ashrrev_i16", d, B, T, ghz, 8);
