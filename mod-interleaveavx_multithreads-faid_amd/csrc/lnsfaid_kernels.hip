@@ -337,7 +337,11 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             s2 a = pk_max(t, (s2)(0) - t);
             u2 key;
             if (LF_MINSUM(METHOD) || LATE_LUT) {
-                key = US((U(a) << 8) | JC(j)); /* |t|; clamped to 7 (and mapped) after the search, CDecoder_OMS.cpp:374 */
+                /* |t| << 8 | code in one instruction, the code from an SGPR (VOP3 takes no literal); |t| is clamped to 7
+                 * (and mapped) after the search, CDecoder_OMS.cpp:374 */
+                uint32_t kk;
+                asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(kk) : "v"(U(a)), "s"(JC(j)));
+                key = US(kk);
             } else {
                 a = pk_min(a, (s2)(SAT_POS_MSG)); /* |t| >= 8 maps through column 7 */
                 if (!UNIW) {
@@ -444,7 +448,8 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             const uint32_t sb = U(US(U(yy)) >> (u2)(15)); /* raw sign s_j per half */
             /* new Lmn = (s_j ^ F) ? -mag : mag, so t + Lmn = t + q * mag with q = 1 - 2 * (s_j ^ F) */
             const s2 en = pk_min(pk_max(pk_mad_i(pk_1_minus_2b(sb ^ Fn01), S(U(mag)), t), (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
-            if (j < 16) nXL |= sb << j; else nXH |= sb << (j - 16);
+            if (j < 16) asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(nXL) : "v"(sb), "n"(j & 15));
+            else asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(nXH) : "v"(sb), "n"(j & 15));
             uint32_t ad = adr[j];
             asm("" : "+v"(ad)); /* row B's address is recomputed here rather than kept in a register since pass 1 */
             en_st(ad, en.x);
