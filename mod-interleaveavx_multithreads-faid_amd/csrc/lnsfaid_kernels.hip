@@ -333,7 +333,9 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
                 yy = pk_mad_i(t, S(c64), E);      /* 64 t + En: sign = sign of (t != 0 ? t : En), back-track :682 */
             }
             y[j] = U(yy);
-            sx ^= U(yy);
+            /* XOR of the signs, two edges per instruction (v_bitop3_b32, truth table 0x96 = a ^ b ^ c) */
+            if (DEG > 0) { if (j & 1) sx = __builtin_amdgcn_bitop3_b32(sx, y[j - 1], U(yy), 0x96); else if (j == DEG - 1) sx ^= U(yy); }
+            else sx ^= U(yy);
             s2 a = pk_max(t, (s2)(0) - t);
             u2 key;
             if (LF_MINSUM(METHOD) || LATE_LUT) {
@@ -433,6 +435,8 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     }
 
     uint32_t nXL = 0, nXH = 0, nIL = 0, nIH = 0;
+    uint32_t one2;
+    asm volatile("s_mov_b32 %0, 0x10001" : "=s"(one2));
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         if (DEG > 0 || j < deg) {
@@ -445,11 +449,12 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
                 if (j < 16) nIL |= im << j; else nIH |= im << (j - 16);
                 mag = pk_mad(ne, C2n - C1n, C1n);
             }
-            const uint32_t sb = U(US(U(yy)) >> (u2)(15)); /* raw sign s_j per half */
-            /* new Lmn = (s_j ^ F) ? -mag : mag, so t + Lmn = t + q * mag with q = 1 - 2 * (s_j ^ F) */
-            const s2 en = pk_min(pk_max(pk_mad_i(pk_1_minus_2b(sb ^ Fn01), S(U(mag)), t), (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
-            if (j < 16) asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(nXL) : "v"(sb), "n"(j & 15));
-            else asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(nXH) : "v"(sb), "n"(j & 15));
+            const uint32_t sm = U(yy >> (s2)(15)); /* raw sign s_j per half as a mask: 0 / 0xffff */
+            /* new Lmn = (s_j ^ F) ? -mag : mag, so t + Lmn = t + q * mag with q = (s_j ^ F) ? -1 : 1 = (mask ^ F) | 1 */
+            const s2 q = S(__builtin_amdgcn_bitop3_b32(sm, Fn, one2, 0xbe)); /* truth table of (a ^ b) | c */
+            const s2 en = pk_min(pk_max(pk_mad_i(q, S(U(mag)), t), (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
+            if (j < 16) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(nXL) : "v"(sm), "s"(0x00010001u << (j & 15)));
+            else asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(nXH) : "v"(sm), "s"(0x00010001u << (j & 15)));
             uint32_t ad = adr[j];
             asm("" : "+v"(ad)); /* row B's address is recomputed here rather than kept in a register since pass 1 */
             en_st(ad, en.x);
