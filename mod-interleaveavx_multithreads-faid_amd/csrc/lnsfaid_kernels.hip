@@ -437,22 +437,35 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     uint32_t nXL = 0, nXH = 0, nIL = 0, nIH = 0;
     uint32_t one2;
     asm volatile("s_mov_b32 %0, 0x10001" : "=s"(one2));
+    uint32_t KA = 0, KB = 0; /* 64 * Lmn (+ 32 where pass 1 left the rounding to pass 2) for s_j = 1 / s_j = 0 */
+    if (METHOD != 0) {
+        const s2 kp = pk_mad_i(S(U(C2n)), S(c64), LF_MINSUM(METHOD) ? (s2)(0) : (s2)(32));
+        const s2 kn = pk_mad_i(S(U(C2n)), (s2)(0) - S(c64), LF_MINSUM(METHOD) ? (s2)(0) : (s2)(32));
+        KA = __builtin_amdgcn_bitop3_b32(Fn, U(kp), U(kn), 0xca); /* s_j = 1: negative unless F */
+        KB = __builtin_amdgcn_bitop3_b32(Fn, U(kn), U(kp), 0xca);
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         if (DEG > 0 || j < deg) {
             const s2 yy = S(y[j]);
-            const s2 t = (LF_MINSUM(METHOD)) ? (yy >> (s2)(6)) : ((yy + (s2)(32)) >> (s2)(6));
-            u2 mag = C2n;
+            const uint32_t sm = U(yy >> (s2)(15)); /* raw sign s_j per half as a mask: 0 / 0xffff */
+            s2 en;
             if (METHOD == 0) { /* by value: every edge with |t| == min1 takes cste_1 (CLDPC.cpp:371-375) */
+                const s2 t = yy >> (s2)(6);
                 const u2 ne = pk_nonzero(U(pk_max(t, (s2)(0) - t)) ^ U(min1));
                 const uint32_t im = U(ne) ^ 0x00010001u;
                 if (j < 16) nIL |= im << j; else nIH |= im << (j - 16);
-                mag = pk_mad(ne, C2n - C1n, C1n);
+                const u2 mag = pk_mad(ne, C2n - C1n, C1n);
+                /* new Lmn = (s_j ^ F) ? -mag : mag, so t + Lmn = t + q * mag with q = (s_j ^ F) ? -1 : 1 = (mask ^ F) | 1 */
+                const s2 q = S(__builtin_amdgcn_bitop3_b32(sm, Fn, one2, 0xbe)); /* truth table of (a ^ b) | c */
+                en = pk_mad_i(q, S(U(mag)), t);
+            } else {
+                /* y = 64 t + r with 0 < r + 32 < 64 (FAID) or r = 32 (min-sum): (y + 64 Lmn [+ 32]) >> 6 = t + Lmn, and every
+                 * edge carries +-c2 (the argmin edge is patched below), so the signed, scaled, rounded addend is one of two
+                 * row constants chosen by the edge's own sign */
+                en = (yy + S(__builtin_amdgcn_bitop3_b32(sm, KA, KB, 0xca))) >> (s2)(6); /* truth table of a ? b : c */
             }
-            const uint32_t sm = U(yy >> (s2)(15)); /* raw sign s_j per half as a mask: 0 / 0xffff */
-            /* new Lmn = (s_j ^ F) ? -mag : mag, so t + Lmn = t + q * mag with q = (s_j ^ F) ? -1 : 1 = (mask ^ F) | 1 */
-            const s2 q = S(__builtin_amdgcn_bitop3_b32(sm, Fn, one2, 0xbe)); /* truth table of (a ^ b) | c */
-            const s2 en = pk_min(pk_max(pk_mad_i(q, S(U(mag)), t), (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
+            en = pk_min(pk_max(en, (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR)); /* :919-920 */
             if (j < 16) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(nXL) : "v"(sm), "s"(0x00010001u << (j & 15)));
             else asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(nXH) : "v"(sm), "s"(0x00010001u << (j & 15)));
             uint32_t ad = adr[j];
