@@ -303,6 +303,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
         en_st(pb, Ep.y);
     }
 
+    const s2 nC2o = (s2)(0) - S(U(C2o));
     uint32_t y[NJ];
     uint32_t adr[NJ];
     uint32_t sx = 0;
@@ -322,15 +323,20 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
                 const uint32_t imb = ((j < 16 ? cur.w : cur.y) >> (j < 16 ? j : j - 16 + 8)) & 0x00010001u;
                 mag = pk_mad(US(imb), C1o - C2o, C2o);
             }
-            /* Lmn = neg ? -mag : mag, so En - Lmn = En + q * mag with q = 2 * neg - 1 */
+            /* Lmn = neg ? -mag : mag with neg = bit j of the sign words, so En - Lmn = En + qn * (-mag), qn = 1 - 2 * neg */
             const uint32_t nb = ((j < 16 ? XL : XH) >> (j & 15)) & 0x00010001u;
-            s2 t = pk_max(pk_mad_i(pk_2b_minus_1(nb), S(U(mag)), E), (s2)(SAT_NEG_VAR)); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
+            const s2 qn = pk_1_minus_2b(nb);
+            s2 t = pk_max(pk_mad_i(qn, METHOD == 0 ? (s2)(0) - S(U(mag)) : nC2o, E), (s2)(SAT_NEG_VAR)); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
             s2 yy;
             if (LF_MINSUM(METHOD)) {
                 yy = pk_mad_i(t, S(c64), S(0x00200020u)); /* 64 t + 32: sign(yy) = (t < 0), CDecoder_OMS.cpp:372 */
             } else {
                 t = pk_min(t, (s2)(SAT_POS_VAR)); /* CDecoder_FAID.cpp:672 */
-                yy = pk_mad_i(t, S(c64), E);      /* 64 t + En: sign = sign of (t != 0 ? t : En), back-track :682 */
+                /* 64 t + qn.  The reference takes the sign of a zero V2C from En (back-track, CDecoder_FAID.cpp:682); t = 0
+                 * means En = Lmn, so that sign is Lmn < 0 = neg (sign bits of zero messages are stored as 0, see the end
+                 * of this function), i.e. the sign of qn.  Reading it from the LDS value would be wrong on the argmin edge,
+                 * whose En is the patched one. */
+                yy = pk_mad_i(t, S(c64), qn);
             }
             y[j] = U(yy);
             /* XOR of the signs, two edges per instruction (v_bitop3_b32, truth table 0x96 = a ^ b ^ c) */
@@ -412,8 +418,8 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     /* ---- the new argmin edge, exactly (its En is still the old value: pass 2 has not started) ---- */
     uint32_t pa = 0, pb = 0, nq = 0;
     s2 en_arg = (s2)(0);
+    const uint32_t ca = U(k1) & 0xffu, cb = (U(k1) >> 16) & 0xffu; /* LF_JCODE_A / _B of the argmin edges */
     if (PATCH) {
-        const uint32_t ca = U(k1) & 0xffu, cb = (U(k1) >> 16) & 0xffu; /* LF_JCODE_A / _B of the argmin edges */
         const uint32_t sba = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ca << 2), (int)sbtab);
         const uint32_t sbb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cb << 2), (int)sbtab);
         pa = bfi(vff, (uint32_t)tid + sba, sba);          /* as vn_offset, operands in VGPRs */
@@ -422,13 +428,14 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
         const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
         const unsigned long long X = ((unsigned long long)XH << 32) | XL;  /* bit LF_JCODE: old message negative */
         const uint32_t nb = ((uint32_t)(X >> ca) & 1u) | (((uint32_t)(X >> cb) & 1u) << 16);
-        s2 t = pk_max(pk_mad_i(pk_2b_minus_1(nb), S(U(C2o)), E), (s2)(SAT_NEG_VAR));
+        const s2 qn = pk_1_minus_2b(nb);
+        s2 t = pk_max(pk_mad_i(qn, nC2o, E), (s2)(SAT_NEG_VAR));
         uint32_t sj;
         if (LF_MINSUM(METHOD)) {
             sj = U(US(U(t)) >> (u2)(15));
         } else {
             t = pk_min(t, (s2)(SAT_POS_VAR));
-            sj = U(US(U(pk_mad_i(t, S(c64), E))) >> (u2)(15));
+            sj = U(US(U(pk_mad_i(t, S(c64), qn))) >> (u2)(15));
         }
         nq = sj ^ Fn01;
         en_arg = pk_min(pk_max(pk_mad_i(pk_1_minus_2b(nq), S(U(C1n)), t), (s2)(SAT_NEG_VAR)), (s2)(SAT_POS_VAR));
@@ -477,6 +484,16 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     if (METHOD == 0) return make_uint4(nXL, nXH | (nIH << 8), (U(C1n) << 5) | (U(C2n) << 8) | (Fn & 0x80008000u), nIL);
     en_st(pa, en_arg.x);
     en_st(pb, en_arg.y);
+    if (!LF_MINSUM(METHOD)) {
+        /* A zero message has no sign: store "not negative" for it, so that the back-track of the next iteration (pass 1)
+         * can read "Lmn < 0" straight from the sign bit.  c2 = 0 zeroes every message of the row but the argmin's. */
+        const uint32_t Z = (U(pk_nonzero(U(C2n))) ^ 0x00010001u) * 0xffffu; /* halves with c2 == 0 */
+        const uint32_t N1 = U(pk_nonzero(U(C1n))) * 0xffffu;                /* halves with c1 != 0 */
+        const unsigned long long oh = (1ull << ca) | (1ull << cb);
+        const uint32_t clrL = Z & ~((uint32_t)oh & N1), clrH = Z & ~((uint32_t)(oh >> 32) & N1);
+        nXL ^= (nXL ^ Fn) & clrL; /* negative = s ^ F: make s = F */
+        nXH ^= (nXH ^ Fn) & clrH;
+    }
     return make_uint4(nXL, nXH, (U(C1n) << 5) | (U(C2n) << 8) | (nq << 11) | (Fn & 0x80008000u), pa | (pb << 16));
 }
 
