@@ -76,8 +76,8 @@ typedef struct lnsfaid_code {
 typedef struct lnsfaid_cfg {
     int32_t decode_method;     /* Profile.txt DecodeMethod 0..5 (README.md:13; 0 = NMS, CLDPC::Decode) */
     int32_t max_iteration;     /* Profile.txt MaxIteration (nb_iteration)           */
-    int32_t factor_1;          /* Profile.txt Factor_1 (selective offset, OMS)      */
-    int32_t factor_2;          /* Profile.txt Factor_2                              */
+    int32_t factor_1;          /* Profile.txt Factor_1: OMS selective offset (>= 0), NMS numerator over 32 of min1 */
+    int32_t factor_2;          /* Profile.txt Factor_2: OMS (>= 1: smaller values leave the 3-bit alphabet, E_INVAL), NMS numerator of min2 */
     int32_t floor_err_count;   /* CDecoder_OMS.cpp:28 (100) / FAID :193 (0) / 2B1C :117 (50) */
     int32_t floor_iter_thresh; /* CDecoder_OMS.cpp:29 (4)  / FAID :194 (-1) / 2B1C :118 (6) */
     int32_t ef_elimination;    /* EF_ELIMINATION 0 (FAID :6) or 1 (2B1C :5)          */

@@ -159,6 +159,10 @@ static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
     out->W = cfg->regular_col_weight;
     out->hard2_thr = cfg->hard2_threshold;
     out->vote_cap = (int8_t)cfg->bf_vote_cap;
+    /* OMS offsets (CDecoder_OMS.cpp:388-425) leave the 3-bit message alphabet for Factor_1 < 0 or Factor_2 < 1: the
+     * minimum 0 would become -1 */
+    if ((cfg->decode_method == 1 || cfg->decode_method == 3 || cfg->decode_method == 4)
+        && ((int8_t)cfg->factor_1 < 0 || (int8_t)cfg->factor_2 < 1)) return LNSFAID_E_INVAL;
     if (cfg->decode_method == 5 && cfg->ef_elimination != 1) return LNSFAID_E_INVAL;
     if (cfg->decode_method == 2 && cfg->ef_elimination != 0) return LNSFAID_E_INVAL;
     out->uniform_w = 1;

@@ -51,3 +51,56 @@ def test_nms_matches_oracle(abi, code50, f1, f2, eb_n0, max_iter):
 @pytest.mark.parametrize("method,max_iter", [(2, 6), (2, 1), (2, 0), (1, 3), (5, 7), (1, 0), (4, 5), (4, 0), (3, 4), (3, 0)])
 def test_iteration_caps(abi, code50, method, max_iter):
     _parity(abi, code50, method, max_iter, 3.6, 2, seed=103)
+
+
+def _set_tables(cfg, rows, ef_rows=None):
+    for it in range(6):
+        for w in range(4):
+            for a in range(8):
+                cfg.v2c_map[it][w][a] = rows[it][a]
+                if ef_rows is not None:
+                    cfg.v2c_map_ef[it][w][a] = ef_rows[it][a]
+
+
+@pytest.mark.parametrize("name", ["faid32", "identity", "steep", "not_monotone", "zero_heavy"])
+@pytest.mark.parametrize("method", [2, 5])
+def test_uniform_table_variants(abi, code50, method, name):
+    """Table sets other than the shipped one, identical for the four weight classes.  Non-decreasing sets take the kernel's
+    table-after-minimum path; large c1 - c2 gaps and tables with LUT[0] != 0 / many zeros stress the argmin patch and the
+    back-track sign (reference CDecoder_FAID.cpp:682); a set that is not monotone must fall back to the per-edge path."""
+    tables = {
+        "faid32": [[0, 1, 1, 2, 3, 3, 3, 3], [0, 1, 1, 2, 3, 3, 3, 3], [0, 1, 1, 2, 4, 4, 4, 4],
+                   [1, 1, 1, 1, 4, 4, 4, 4], [1, 1, 1, 1, 5, 5, 5, 5], [1, 1, 1, 1, 6, 6, 6, 6]],  # CDecoder_FAID.cpp:51-88
+        "identity": [[0, 1, 2, 3, 4, 5, 6, 7]] * 6,
+        "steep": [[0, 0, 0, 7, 7, 7, 7, 7], [0, 0, 5, 5, 5, 7, 7, 7], [0, 3, 3, 3, 6, 6, 7, 7]] * 2,
+        "not_monotone": [[0, 2, 1, 3, 3, 3, 7, 7], [0, 1, 1, 2, 3, 3, 3, 3], [1, 0, 1, 2, 4, 4, 4, 4]] * 2,
+        "zero_heavy": [[0, 0, 0, 0, 3, 3, 3, 3], [0, 0, 1, 1, 3, 3, 5, 5], [0, 0, 0, 2, 2, 2, 6, 6]] * 2,
+    }[name]
+    cfg = abi.default_cfg(method, 10)
+    _set_tables(cfg, tables, [[1, 2, 2, 4, 5, 6, 6, 7]] * 6 if method == 5 else None)
+    for eb_n0, seed in [(3.3, 151), (3.7, 157)]:
+        fix = oa.ReferenceChannel(code50, seed, 13.0).groups(eb_n0, 3)
+        ref, ref_stats = oa.Oracle(code50, cfg).decode(fix, 3)
+        dec = abi.Decoder(code50, cfg, device=0, max_groups=3)
+        out, stats = dec.decode(fix, 3)
+        dec.close()
+        assert np.array_equal(out, ref), (name, method, eb_n0)
+        assert np.array_equal(stats, ref_stats)
+
+
+@pytest.mark.parametrize("f1,f2", [(1, 2), (3, 3), (0, 1), (5, 2), (7, 7)])
+@pytest.mark.parametrize("method", [1, 4])
+def test_oms_offset_corner_factors(abi, code50, method, f1, f2):
+    """Factor pairs that make the selective offset non-monotone in the minimum (f2 <= f1 + 1) or zero most messages.
+    Factor_2 < 1 would turn the minimum 0 into -1 (outside the message alphabet): rejected at configuration time."""
+    cfg = abi.default_cfg(method, 8)
+    cfg.factor_1, cfg.factor_2 = 0, 0
+    with pytest.raises(RuntimeError):
+        abi.Decoder(code50, cfg, device=0, max_groups=2)
+    cfg.factor_1, cfg.factor_2 = f1, f2
+    fix = oa.ReferenceChannel(code50, 163, 13.0).groups(3.5, 2)
+    ref, ref_stats = oa.Oracle(code50, cfg).decode(fix, 2)
+    dec = abi.Decoder(code50, cfg, device=0, max_groups=2)
+    out, stats = dec.decode(fix, 2)
+    dec.close()
+    assert np.array_equal(out, ref) and np.array_equal(stats, ref_stats)
