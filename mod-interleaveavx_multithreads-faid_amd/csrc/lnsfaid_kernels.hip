@@ -254,10 +254,11 @@ __device__ __forceinline__ int oms_offset(int x, bool window, bool F, int f1, in
 /* ---- one layered iteration (FAID / 2B1C: CDecoder_FAID.cpp:631-1527; OMS: CDecoder_OMS.cpp:334-743; NMS:
  * CLDPC.cpp:287-2283) -----------------------------------------------------------------------------------------
  * rows: this codeword's compressed messages, [nbr][128] uint4 for the row pair (tid, tid+128); 16-bit halves:
- *   .x bit j (j < 16), .y bit j-16: raw sign s_j of the V2C on edge j, low half row A, high half row B
- *   .z per half: c1 << 5 | c2 << 8 | n << 11 | F << 15, F = XOR_all(s) ^ (deg odd), n = s ^ F of the argmin edge
+ *   .x bit j (j < 16), .y bit j-16: Lmn on edge j is negative (= s_j ^ F: s_j the sign of the V2C, F = XOR_all(s) ^
+ *      (deg odd)); 0 for a zero message (FAID / 2B1C); low half row A, high half row B
+ *   .z per half: c1 << 5 | c2 << 8 | n << 11, n = the argmin edge's message is negative
  *   .w per half: LDS offset of the argmin edge's variable node
- *   Lmn(edge j) = (j == argmin ? c1 : c2), negative iff s_j ^ F
+ *   Lmn(edge j) = (j == argmin ? c1 : c2) with that sign
  * DecodeMethod 0 keeps a by-value mask instead (its two constants use different factors):
  *   .w bit j / .y bit 8 + j - 16: |t_j| == min1, no argmin fields.
  *
@@ -286,8 +287,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     constexpr bool LATE_LUT = !LF_MINSUM(METHOD) && UNIW;
     uint32_t selk = 0;
     if (!LF_MINSUM(METHOD) && !UNIW) asm volatile("v_mov_b32 %0, 0x06020400" : "=v"(selk)); /* key = {m.b2, code.b2, m.b0, code.b0} */
-    const uint32_t Fo = U(S(cur.z) >> (s2)(15)); /* 0 / 0xffff per half */
-    const uint32_t XL = cur.x ^ Fo, XH = cur.y ^ Fo;
+    const uint32_t XL = cur.x, XH = cur.y; /* bit j: Lmn on edge j is negative */
     const u2 C1o = US((cur.z >> 5) & 0x00070007u), C2o = US((cur.z >> 8) & 0x00070007u);
     uint32_t c64;
     asm volatile("v_mov_b32 %0, 0x400040" : "=v"(c64)); /* packed 64 kept in a VGPR for v_pk_mad_i16 */
@@ -481,9 +481,10 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             en_st(ad ^ 128u, en.y);
         }
     }
-    if (METHOD == 0) return make_uint4(nXL, nXH | (nIH << 8), (U(C1n) << 5) | (U(C2n) << 8) | (Fn & 0x80008000u), nIL);
+    if (METHOD == 0) return make_uint4(nXL ^ Fn, ((nXH ^ Fn) & 0x00ff00ffu) | (nIH << 8), (U(C1n) << 5) | (U(C2n) << 8), nIL);
     en_st(pa, en_arg.x);
     en_st(pb, en_arg.y);
+    /* the new Lmn on edge j is negative iff s_j ^ F */
     if (!LF_MINSUM(METHOD)) {
         /* A zero message has no sign: store "not negative" for it, so that the back-track of the next iteration (pass 1)
          * can read "Lmn < 0" straight from the sign bit.  c2 = 0 zeroes every message of the row but the argmin's. */
@@ -491,10 +492,13 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
         const uint32_t N1 = U(pk_nonzero(U(C1n))) * 0xffffu;                /* halves with c1 != 0 */
         const unsigned long long oh = (1ull << ca) | (1ull << cb);
         const uint32_t clrL = Z & ~((uint32_t)oh & N1), clrH = Z & ~((uint32_t)(oh >> 32) & N1);
-        nXL ^= (nXL ^ Fn) & clrL; /* negative = s ^ F: make s = F */
-        nXH ^= (nXH ^ Fn) & clrH;
+        nXL = __builtin_amdgcn_bitop3_b32(nXL, Fn, clrL, 0x14); /* (a ^ b) & ~c */
+        nXH = __builtin_amdgcn_bitop3_b32(nXH, Fn, clrH, 0x14);
+    } else {
+        nXL ^= Fn;
+        nXH ^= Fn;
     }
-    return make_uint4(nXL, nXH, (U(C1n) << 5) | (U(C2n) << 8) | (nq << 11) | (Fn & 0x80008000u), pa | (pb << 16));
+    return make_uint4(nXL, nXH, (U(C1n) << 5) | (U(C2n) << 8) | (nq << 11), pa | (pb << 16));
 }
 
 template <int METHOD, bool UNIW>
