@@ -187,6 +187,11 @@ uint64_t lnsfaid_frontend_draws_per_group(const lnsfaid_ctx* ctx, int32_t mod_ty
  * device allocator (host/CLDPC.cpp) runs front-end -> decode -> counters on them with the *_device entry points. */
 int lnsfaid_io_buffers(lnsfaid_ctx* ctx, int8_t** d_fixInput, int8_t** d_decodedBits, lnsfaid_group_stats** d_stats);
 
+/* Copy the per-group iteration counts a *_device decode left in the context's statistics buffer (the d_stats of
+ * lnsfaid_io_buffers) to the host: what Decode_OMSBF / Decode_OMS_DTBF return as BFiter (reference CLDPC.h:150-151,
+ * histogrammed into iterCount.txt by CSimulate.cpp:148-178) when the decoded frames themselves stay on the device. */
+int lnsfaid_read_stats(lnsfaid_ctx* ctx, lnsfaid_group_stats* stats, size_t n_groups);
+
 /* ---- measurement hooks ------------------------------------------------------- */
 
 /* Device time (HIP events on the context's stream) and launch count of the

@@ -345,6 +345,18 @@ extern "C" int lnsfaid_io_buffers(lnsfaid_ctx* ctx, int8_t** d_fixInput, int8_t*
     return LNSFAID_OK;
 }
 
+extern "C" int lnsfaid_read_stats(lnsfaid_ctx* ctx, lnsfaid_group_stats* stats, size_t n_groups)
+{
+    if (!ctx || (n_groups && !stats) || n_groups > ctx->max_groups) return LNSFAID_E_INVAL;
+    if (n_groups == 0) return LNSFAID_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int rc = ensure_io(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(stats, ctx->d_io_stats, n_groups * sizeof(lnsfaid_group_stats), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LNSFAID_OK;
+}
+
 extern "C" int lnsfaid_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, size_t n_groups, int8_t* decodedBits,
                               lnsfaid_group_stats* stats)
 {

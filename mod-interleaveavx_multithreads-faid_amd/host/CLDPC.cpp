@@ -1,5 +1,8 @@
 #include "CLDPC.h"
 
+#include <fstream>
+#include <vector>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -97,7 +100,8 @@ void CLDPC::decode_with(int method)
         lnsfaid_group_stats* d_st = nullptr;
         rc = lnsfaid_io_buffers(ctx, &d_fix, &d_out, &d_st);
         if (rc) die("lnsfaid_io_buffers", rc);
-        rc = lnsfaid_decode_device(ctx, d_fix, (size_t)m_groups, d_out, nullptr);
+        rc = lnsfaid_decode_device(ctx, d_fix, (size_t)m_groups, d_out, d_st);
+        if (!rc) rc = lnsfaid_read_stats(ctx, m_stats, (size_t)m_groups); /* 8 bytes per group: iteration counts, BFiter */
     } else {
         rc = lnsfaid_decode(ctx, fixInput, (size_t)m_groups, decodedBits, m_stats);
     }
@@ -125,8 +129,66 @@ void CLDPC::Decode() { decode_with(0); }
 void CLDPC::Decode_OMS() { decode_with(1); }
 void CLDPC::Decode_FAID() { decode_with(2); }
 void CLDPC::Decode_FAID_2B1C() { decode_with(5); }
-int CLDPC::Decode_OMSBF() { decode_with(3); return m_device_io ? 0 : m_stats[0].bf_iterations; }
-int CLDPC::Decode_OMS_DTBF() { decode_with(4); return m_device_io ? 0 : m_stats[0].bf_iterations; }
+int CLDPC::Decode_OMSBF() { decode_with(3); return m_stats[0].bf_iterations; }
+int CLDPC::Decode_OMS_DTBF() { decode_with(4); return m_stats[0].bf_iterations; }
+
+/* The collect-flag dump of reference CLDPC.cpp:4877-4983: one record per frame with information-bit errors appended to
+ * errorindex.txt (block / index of every wrong information and parity bit), errorfloat.txt (channel output and 4-bit
+ * input of the frame) and errordecode.txt (decoded, sent information and sent code bits).  bpskinput has the fixInput
+ * layout ([32][K] then [32][M] per group); the reference's Z is Profile.txt's. */
+void CLDPC::CollectErrors(const float* bpskinput, int Z)
+{
+    if (m_device_io) {
+        static bool warned = false;
+        if (!warned) fprintf(stderr, "collectflag: frames stay on the device with --device-frontend, no error dumps are written\n");
+        warned = true;
+        return;
+    }
+    const int N = m_N, K = m_K, M = m_M;
+    std::vector<int> bit_block, bit_index, chk_block, chk_index;
+    for (int g = 0; g < m_groups; ++g) {
+        const int8_t* dec = decodedBits + (size_t)g * 32 * N;
+        const int8_t* in = inputBits + (size_t)g * 32 * K;
+        const int8_t* outb = outputBits + (size_t)g * 32 * N;
+        const int8_t* chr = fixInput + (size_t)g * 32 * N;
+        const float* flt = bpskinput ? bpskinput + (size_t)g * 32 * N : nullptr;
+        for (int i = 0; i < 32; ++i) {
+            bit_block.clear(); bit_index.clear(); chk_block.clear(); chk_index.clear();
+            for (int j = 0; j < K; ++j)
+                if (dec[(size_t)i * N + j] != in[(size_t)i * K + j]) { bit_block.push_back(j / Z + 1); bit_index.push_back(j % Z); }
+            if (bit_block.empty()) continue;
+            for (int j = K; j < N; ++j)
+                if (dec[(size_t)i * N + j] != outb[(size_t)32 * K + (size_t)i * M + (j - K)]) { chk_block.push_back(j / Z + 1); chk_index.push_back(j % Z); }
+            std::ofstream eout("errorindex.txt", std::ios::app), nout("errorfloat.txt", std::ios::app), dout("errordecode.txt", std::ios::app);
+            eout << "ErrorFrame: " << i << std::endl << "ErrorBit Num: " << bit_block.size() << std::endl << "Errorbit Block: ";
+            for (int v : bit_block) eout << v << "\t";
+            eout << std::endl << "Errobit Index: ";
+            for (int v : bit_index) eout << v << "\t";
+            eout << std::endl << "Errorcheck Num: " << chk_block.size() << std::endl << "Errorcheck Block: ";
+            for (int v : chk_block) eout << v << "\t";
+            eout << std::endl << "Errorcheck Index: ";
+            for (int v : chk_index) eout << v << "\t";
+            eout << std::endl;
+            nout << "ErrorFloat=[ ";
+            if (flt) {
+                for (int j = 0; j < K; ++j) nout << flt[(size_t)i * K + j] << "\t";
+                for (int j = 0; j < M; ++j) nout << flt[(size_t)32 * K + (size_t)i * M + j] << "\t";
+            }
+            nout << "];" << std::endl << "ErrorChar=[";
+            for (int j = 0; j < K; ++j) nout << (int)chr[(size_t)i * K + j] << "\t";
+            for (int j = 0; j < M; ++j) nout << (int)chr[(size_t)32 * K + (size_t)i * M + j] << "\t";
+            nout << "];" << std::endl << std::endl;
+            dout << "Decodedbits=[";
+            for (int j = 0; j < N; ++j) dout << (int)dec[(size_t)i * N + j] << "\t";
+            dout << "];" << std::endl << "inputbits=[";
+            for (int j = 0; j < K; ++j) dout << (int)in[(size_t)i * K + j] << "\t";
+            dout << "];" << std::endl << "outputbits=[";
+            for (int j = 0; j < K; ++j) dout << (int)outb[(size_t)i * K + j] << "\t";
+            for (int j = 0; j < M; ++j) dout << (int)outb[(size_t)32 * K + (size_t)i * M + j] << "\t";
+            dout << "];" << std::endl << std::endl;
+        }
+    }
+}
 
 Statistic CLDPC::CalculateErrors()
 {

@@ -51,6 +51,9 @@ public:
     int Decode_OMSBF();      /* DecodeMethod 3; returns the bit-flipping iterations of the first group */
     int Decode_OMS_DTBF();   /* DecodeMethod 4; returns the bit-flipping iterations of the first group (reference: BFiter) */
     Statistic CalculateErrors();
+    /* collectflag == 1 part of the reference's CalculateErrors(bpskinput, charinput, collectflag) (CLDPC.h:169):
+     * appends the error frames of the last decode to errorindex.txt / errorfloat.txt / errordecode.txt */
+    void CollectErrors(const float* bpskinput, int Z);
 
     /* Device-resident mode (--device-frontend): the channel output of `m_groups` reference worker threads is
      * generated on the GPU straight into the decoder's input buffer, Decode_*() and CalculateErrors() then work on

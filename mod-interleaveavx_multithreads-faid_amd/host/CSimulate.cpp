@@ -1,5 +1,8 @@
 #include "CSimulate.h"
 
+#include <algorithm>
+#include <fstream>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -30,6 +33,7 @@ void CSimulate::Initial(Parameter_Simulation& p, int first_index, int streams, i
     scale = p.scale;
     m_first = first_index;
     m_streams = streams;
+    m_Z = p.Z > 0 ? p.Z : 256;
     ModulationType = p.mod_type;
     InterleaveModType = p.interleavemod_type;
     if ((ModulationType != 1 && ModulationType != 2 && ModulationType != 4) || InterleaveModType != 1) {
@@ -91,6 +95,7 @@ void CSimulate::Run()
         }
     }
     std::vector<float> llr(device_frontend ? 0 : (size_t)m_streams * bits);
+    std::vector<int> BFiters_((size_t)m_streams * 51, 0); /* per stream, reference CSimulate.cpp:99 */
     std::vector<uint32_t> seeds(m_streams);
     for (int s = 0; s < m_streams; ++s) seeds[s] = (uint32_t)channel[s].RandomSeed;
     for (int call = 0; call < 50; ++call) {
@@ -149,12 +154,34 @@ void CSimulate::Run()
         default: ldpc->Decode(); break; /* as the reference: any other value runs NMS */
         }
         decode_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (!device_frontend)
-            for (int s = 0; s < m_streams; ++s) { sum_iterations += ldpc->GroupStats()[s].iterations; sum_bf_iterations += ldpc->GroupStats()[s].bf_iterations; }
+        for (int s = 0; s < m_streams; ++s) {
+            const lnsfaid_group_stats& st = ldpc->GroupStats()[s];
+            sum_iterations += st.iterations; sum_bf_iterations += st.bf_iterations;
+            /* BF_ITER_COUNT (reference CSimulate.cpp:146-156): only DecodeMethod 3 and 4 return BFiter */
+            if ((decode_method == 3 || decode_method == 4) && st.bf_iterations >= 0 && st.bf_iterations <= 50) BFiters_[(size_t)s * 51 + st.bf_iterations]++;
+        }
         decoded_groups += m_streams;
         const Statistic Test = ldpc->CalculateErrors();
         ErrorFrame += Test.ErrorFrame;
         ErrorBits += Test.ErrorBits;
         LT3ErrBitFrame += Test.LT3ErrBitFrame;
+        if (collectflag == 1 && Test.ErrorFrame > 0) { /* reference CLDPC.cpp:4877: set by main once FER < 1e-5 */
+            std::vector<float> fl; /* DeInterLeaveSeq layout: [32][K] then [32][M] per group */
+            if (!device_frontend) {
+                fl.resize((size_t)m_streams * bits);
+                for (int s = 0; s < m_streams; ++s)
+                    for (int m = 0; m < 32; ++m) {
+                        const float* src = llr.data() + (size_t)s * bits + (size_t)m * N;
+                        std::copy(src, src + K, fl.data() + (size_t)s * bits + (size_t)m * K);
+                        std::copy(src + K, src + N, fl.data() + (size_t)s * bits + (size_t)32 * K + (size_t)m * M);
+                    }
+            }
+            ldpc->CollectErrors(fl.empty() ? nullptr : fl.data(), m_Z);
+        }
     }
+    /* reference CSimulate.cpp:171-179: every worker appends its histogram after its 50 calls */
+    std::ofstream iterOut("iterCount.txt", std::ios::app);
+    for (int s = 0; s < m_streams; ++s)
+        for (int i = 1; i <= 50; i++)
+            if (BFiters_[(size_t)s * 51 + i] != 0) iterOut << i << ": " << BFiters_[(size_t)s * 51 + i] << std::endl;
 }

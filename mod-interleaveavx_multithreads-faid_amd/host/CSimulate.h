@@ -35,7 +35,7 @@ public:
 private:
     std::vector<Complex8> ModSeq;   /* modulated fixed codeword of one group (QPSK) */
     std::vector<float> BPSKModSeq;
-    int m_first = 0, m_streams = 0;
+    int m_first = 0, m_streams = 0, m_Z = 256;
     std::vector<uint64_t> m_draws; /* uniforms consumed per stream (device front-end) */
 };
 

@@ -32,7 +32,7 @@ int main(int argc, char** argv)
      * threads while the GPU decodes (set before the OpenMP runtime starts) */
     setenv("OMP_WAIT_POLICY", "passive", 0);
     int streams = 64, gpus = 1, max_rounds = 0;
-    bool device_frontend = false;
+    bool device_frontend = false, force_collect = false;
     const char* profile = "Profile.txt";
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--streams") && i + 1 < argc) streams = atoi(argv[++i]);
@@ -40,7 +40,8 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--profile") && i + 1 < argc) profile = argv[++i];
         else if (!strcmp(argv[i], "--max-rounds") && i + 1 < argc) max_rounds = atoi(argv[++i]); /* 0 = reference stop rule only */
         else if (!strcmp(argv[i], "--device-frontend")) device_frontend = true; /* channel + demapper + quantiser on the GPU */
-        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R] [--device-frontend]\n", argv[0]); return 2; }
+        else if (!strcmp(argv[i], "--collect")) force_collect = true; /* collectflag = 1 from the first call (reference: once FER < 1e-5) */
+        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R] [--device-frontend] [--collect]\n", argv[0]); return 2; }
     }
     if (streams < 1 || gpus < 1 || gpus > streams) { fprintf(stderr, "need 1 <= gpus <= streams\n"); return 2; }
 
@@ -81,6 +82,11 @@ int main(int argc, char** argv)
     for (float snr = p_simulation.snr_start; snr < p_simulation.snr_end; snr += p_simulation.snr_pass) {
         unsigned long TestFrame = 0, ErrorFrame = 0, ErrorBits = 0, LT3ErrBitFrame = 0;
         double BER = 0, FER = 0, decode_s = 0;
+        for (const char* name : { "iterCount.txt", "errorindex.txt", "errorfloat.txt", "errordecode.txt" }) { /* reference main.cpp:145-157 */
+            ofstream f(name, std::ios::app);
+            f << "Eb/N0: " << setw(5) << snr << "scale=" << p_simulation.scale << endl;
+        }
+        if (force_collect) collectflag = 1;
         for (auto& s : simulate) { s.Configure(snr, p_simulation.decode_method); s.decode_seconds = 0; }
         timeval t_start, t_end;
         gettimeofday(&t_start, NULL);
@@ -94,6 +100,7 @@ int main(int argc, char** argv)
             }
             BER = (double)(ErrorBits > 0 ? ErrorBits : 1) / ((double)TestFrame * (NmoinsK - _ShortenBits));
             FER = (double)(ErrorFrame > 0 ? ErrorFrame : 1) / TestFrame;
+            if (FER < 1E-5 || force_collect) collectflag = 1; /* reference main.cpp:190-192: dump the error frames from here on */
             ofstream tout("Temp.txt", std::ios::out);
             tout << setw(5) << snr << '\t' << setw(20) << TestFrame << '\t' << setw(15) << ErrorFrame << '\t' << setw(20) << ErrorBits << '\t'
                  << setw(20) << FER << '\t' << setw(20) << BER << '\t' << setw(15) << LT3ErrBitFrame << '\t' << endl;

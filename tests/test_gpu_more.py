@@ -210,6 +210,69 @@ def test_host_driver_sweep_point_matches_oracle(abi, code50, tmp_path, mod_type,
     assert (tmp_path / "Result.txt").exists() and (tmp_path / "Temp.txt").exists()
 
 
+@pytest.mark.parametrize("extra", [[], ["--device-frontend"]], ids=["host_frontend", "device_frontend"])
+def test_host_driver_result_files(abi, code50, tmp_path, extra):
+    """N4: iterCount.txt (BF-iteration histogram of DecodeMethod 3 / 4, reference CSimulate.cpp:146-178) and the
+    collect-flag dumps of CalculateErrors (errorindex / errorfloat / errordecode.txt, reference CLDPC.cpp:4877-4983),
+    forced on from the first call with --collect (the reference switches them on once FER < 1e-5)."""
+    exe = os.path.join(oa.PKG_DIR, "host", "lnsfaid_sim")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(oa.PKG_DIR, "host")])
+    eb_n0, method = 3.45, 4
+    prof = open(os.path.join(oa.PKG_DIR, "host", "Profile.txt")).read()
+    prof = prof.replace("StartSNR: 3.3", "StartSNR: %g" % eb_n0).replace("EndSNR: 3.85", "EndSNR: %g" % (eb_n0 + 0.05))
+    prof = prof.replace("DecodeMethod: 2", "DecodeMethod: %d" % method)
+    (tmp_path / "Profile.txt").write_text(prof)
+    res = subprocess.run([exe, "--streams", "2", "--gpus", "1", "--max-rounds", "1", "--collect"] + extra, cwd=tmp_path,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    cfg = abi.default_cfg(method, 10)
+    hist, records = {}, []
+    for seed in [101, 103]:
+        fix = oa.ReferenceChannel(code50, seed, 13.0).groups(eb_n0, 50)
+        dec, st = oa.decode_mt(code50, cfg, fix, 50, kind="avx2")
+        for j in st[:, 1]:
+            if j:
+                hist[int(j)] = hist.get(int(j), 0) + 1
+        d = dec.reshape(50, 32, code50.N)
+        for g in range(50):
+            for i in range(32):
+                bad = np.nonzero(d[g, i, :code50.K])[0]
+                if bad.size:
+                    records.append((seed, g, i, bad, np.nonzero(d[g, i, code50.K:])[0] + code50.K, d[g, i]))
+    lines = (tmp_path / "iterCount.txt").read_text().splitlines()
+    assert lines[0].startswith("Eb/N0:")
+    got = {}
+    for l in lines[1:]:
+        k, v = l.split(":")
+        got[int(k)] = got.get(int(k), 0) + int(v)
+    assert got == hist
+    if extra:  # frames stay on the device: headers only, and a warning
+        assert "no error dumps" in res.stderr
+        assert len((tmp_path / "errorindex.txt").read_text().splitlines()) == 1
+        return
+    idx = (tmp_path / "errorindex.txt").read_text().splitlines()[1:]
+    assert len(idx) == 7 * len(records)
+    # the driver walks call by call with both streams inside: order records by (call, stream, frame)
+    records.sort(key=lambda r: (r[1], [101, 103].index(r[0]), r[2]))
+    for n, (seed, g, i, bad, badc, bits) in enumerate(records):
+        rec = idx[7 * n:7 * n + 7]
+        assert rec[0] == "ErrorFrame: %d" % i and rec[1] == "ErrorBit Num: %d" % bad.size
+        assert [int(x) for x in rec[2].split(":")[1].split()] == (bad // 256 + 1).tolist()
+        assert [int(x) for x in rec[3].split(":")[1].split()] == (bad % 256).tolist()
+        assert rec[4] == "Errorcheck Num: %d" % badc.size
+        assert [int(x) for x in rec[5].split(":")[1].split()] == (badc // 256 + 1).tolist()
+    dec_lines = [l for l in (tmp_path / "errordecode.txt").read_text().splitlines() if l.startswith("Decodedbits=[")]
+    assert len(dec_lines) == len(records)
+    assert [int(x) for x in dec_lines[0][len("Decodedbits=["):-2].split()] == records[0][5].tolist()
+    fl = [l for l in (tmp_path / "errorfloat.txt").read_text().splitlines() if l.startswith("ErrorChar=[")]
+    assert len(fl) == len(records)
+    seed, g, i = records[0][:3]
+    fix = oa.ReferenceChannel(code50, seed, 13.0).groups(eb_n0, 50).reshape(50, -1)[g]
+    want = np.concatenate([fix[i * code50.K:(i + 1) * code50.K], fix[32 * code50.K + i * code50.M:32 * code50.K + (i + 1) * code50.M]])
+    assert [int(x) for x in fl[0][len("ErrorChar=["):-2].split()] == want.tolist()
+
+
 def _derived_code(abi, lib, drop_cols, from_block_row):
     """A second quasi-cyclic code for the generic code paths: the 50G-PON table with the circulants of the
     block columns `drop_cols` removed from block rows >= from_block_row (degree 23 -> 23 - len(drop_cols))."""
