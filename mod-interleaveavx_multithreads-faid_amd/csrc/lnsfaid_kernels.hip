@@ -159,9 +159,27 @@ template <bool CONF>
 __device__ void build_plane(CCode c, const int8_t* sEn, uint32_t* plane, int thr, int tid)
 {
     const int N = c->n_var;
-    for (int base = 0; base < N; base += LF_T) {
+    constexpr int U = 8; /* LDS reads in flight per thread: the loop is a chain of LDS round trips otherwise */
+    int base = 0;
+    for (; base + U * LF_T <= N; base += U * LF_T) {
+        int e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) e[u] = en_ld((uint32_t)(base + u * LF_T + tid));
+        unsigned long long h[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) h[u] = CONF ? __ballot(e[u] >= thr || e[u] <= -thr) : __ballot(e[u] > 0);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int w = (base + u * LF_T + tid) >> 5;
+                plane[w] = (uint32_t)h[u];
+                plane[w + 1] = (uint32_t)(h[u] >> 32);
+            }
+        }
+    }
+    for (; base < N; base += LF_T) {
         const int v = base + tid;
-        const int e = sEn[v];
+        const int e = en_ld((uint32_t)v);
         const unsigned long long h = CONF ? __ballot(e >= thr || e <= -thr) : __ballot(e > 0);
         if ((tid & 63) == 0) {
             const int w = v >> 5;
