@@ -121,6 +121,23 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
         }
         e += (size_t)deg * Z;
     }
+    {   /* syndrome walk table: needs the LDS layout (n_words = N / 32, p_words = M / 32) */
+        const int nw = N / 32, pw = M / 32;
+        const uint32_t hard0 = lf_lds_off_hard(N), zero = lf_lds_off_zero(N, nw, pw);
+        if (lf_lds_bytes(N, nw, pw) > 0xffffu) return LNSFAID_E_CODE; /* 16-bit addresses */
+        for (int br = 0; br < LF_MAX_BR; ++br)
+            for (int j = 0; j < LF_MAX_DEG; ++j)
+                for (int k = 0; k < 8; ++k) {
+                    uint2 e; e.x = zero | (zero << 16); e.y = 0;
+                    if (br < nbr && j < out->deg[br]) {
+                        const uint32_t sb = out->circ[br][j].sb, cb = sb / (uint32_t)Z, sh = sb % (uint32_t)Z;
+                        const uint32_t o = (32u * (uint32_t)k + sh) & 255u, q = o >> 5;
+                        e.x = (hard0 + 4u * (cb * 8u + q)) | ((hard0 + 4u * (cb * 8u + ((q + 1u) & 7u))) << 16);
+                        e.y = o & 31u;
+                    }
+                    out->synw[br][j][k] = e;
+                }
+    }
     for (int br = 0; br < nbr; ++br)
         for (int j = 0; j < out->deg[br]; ++j)
             out->circ[br][j].wclass = (uint32_t)weight_class(out->col_weight[out->circ[br][j].sb / (uint32_t)Z]);

@@ -37,6 +37,9 @@ struct LfDevCode {
     int32_t deg[LF_MAX_BR];
     LfCirc circ[LF_MAX_BR][LF_MAX_DEG];
     uint32_t sbtab[LF_MAX_BR][64];            /* lane LF_JCODE_A(j) and lane LF_JCODE_B(j): circ[br][j].sb              */
+    uint2 synw[LF_MAX_BR][LF_MAX_DEG][8];     /* syndrome walk, per (layer, circulant, 32-row word k): .x = LDS byte addresses of
+                                               * the two hard-plane words holding bits (32k + shift) mod 256 ... + 31 of the block
+                                               * column (low / high 16 bits), .y = bit offset; unused slots: the zero word, 0     */
     uint32_t syn[LF_MAX_BR][32];              /* lane j: shift | block column << 8 of circulant j, ~0u beyond deg */
     int32_t col_weight[LF_MAX_BC];
     int32_t wcol[LF_MAX_BC];                  /* the n_wcols block columns of weight W                           */
@@ -87,6 +90,11 @@ static inline __host__ __device__ uint32_t lf_lds_off_p(int n_var, int n_words) 
 static inline __host__ __device__ uint32_t lf_lds_off_stat(int n_var, int n_words, int p_words)
 {
     return (lf_lds_off_p(n_var, n_words) + ((uint32_t)p_words + 2u) * 4u + 7u) & ~7u;
+}
+#define LF_ZERO_SLOT 7 /* reduction-scratch word that is zeroed at kernel entry and never written again */
+static inline __host__ __device__ uint32_t lf_lds_off_zero(int n_var, int n_words, int p_words)
+{
+    return lf_lds_off_stat(n_var, n_words, p_words) + (LNSFAID_GROUP + LF_ZERO_SLOT) * 4u;
 }
 static inline __host__ __device__ uint32_t lf_lds_bytes(int n_var, int n_words, int p_words)
 {

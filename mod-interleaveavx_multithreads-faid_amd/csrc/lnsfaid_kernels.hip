@@ -190,40 +190,56 @@ __device__ void build_plane(CCode c, const int8_t* sEn, uint32_t* plane, int thr
     __syncthreads();
 }
 
-/* ---- bit-parallel syndrome of a hard-decision plane (CDecoder_FAID.cpp:291-343, :6443-6491) ---------------
- * Wave w owns rows [64w, 64w+64) and [128+64w, 128+64w+64) of every layer; lane j < deg fetches the two
- * 64-bit windows that circulant j contributes, the XOR over the lanes is the parity of those 128 rows.
- * Writes the parity plane sP (bit r = l_checksum_[r]), returns the number of unsatisfied checks; pA / pB get
- * bit br = parity of this thread's rows tid / tid + 128 in layer br. */
-__device__ int syndrome(CCode c, const LfDevCode* gc, const uint32_t* plane, uint32_t* sP, int tid, uint32_t& pA,
-                        uint32_t& pB, int* sRed)
+/* sum over lanes 0..31 / 32..63 of a wave, results in lanes 31 / 63 (same DPP pattern as xor_reduce32) */
+__device__ __forceinline__ int add_reduce32(int v)
 {
-    const int w = tid >> 6, lane = tid & 63;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1, 3 */
+    return v;
+}
+
+/* ---- bit-parallel syndrome of the hard-decision plane sHard (CDecoder_FAID.cpp:291-343, :6443-6491) -----------
+ * The parity of the 32 rows [32k, 32k+32) of layer br is the XOR over the row's circulants of 32 consecutive (mod 256)
+ * bits of the circulant's block column.  One lane per (layer, k): it walks the layer's circulants with a host-built
+ * table of {LDS addresses of the two plane words, bit offset} (LfDevCode::synw), two ds_read_b32 + one v_alignbit_b32
+ * + one v_xor per circulant and no cross-lane reduction; slots beyond the row degree point at a zero word.
+ * Writes the parity plane sP (bit r = l_checksum_[r]), returns the number of unsatisfied checks; with ROWBITS pA / pB
+ * get bit br = parity of this thread's rows tid / tid + 128 in layer br (the error-floor tables need them). */
+template <bool ROWBITS>
+__device__ int syndrome(CCode c, const LfDevCode* gc, uint32_t* sP, int tid, uint32_t& pA, uint32_t& pB, int* sRed)
+{
+    typedef const __attribute__((address_space(3))) uint32_t lds_u32;
     const int nbr = c->nbr;
-    uint32_t a = 0, b = 0;
     int cnt = 0;
-    /* lanes 0..31 fetch the windows of rows [64w, 64w+64), lanes 32..63 those of rows [128+64w, ...) */
-    const uint32_t half_off = 64u * (uint32_t)w + ((lane & 32) ? 128u : 0u);
-    uint32_t nxt = gc->syn[0][lane & 31]; /* lane-indexed: vector load, one layer ahead */
-    for (int br = 0; br < nbr; ++br) {
-        const uint32_t e = nxt;
-        if (br + 1 < nbr) nxt = gc->syn[br + 1][lane & 31];
-        uint32_t lo = 0, hi = 0;
-        if (e != 0xffffffffu) window64(plane + (e >> 8) * 8u, ((e & 0xffu) + half_off) & 255u, lo, hi);
-        lo = xor_reduce32(lo); hi = xor_reduce32(hi); /* lane 31: rows A, lane 63: rows B */
-        const uint32_t rloA = __builtin_amdgcn_readlane(lo, 31), rhiA = __builtin_amdgcn_readlane(hi, 31);
-        const uint32_t rloB = __builtin_amdgcn_readlane(lo, 63), rhiB = __builtin_amdgcn_readlane(hi, 63);
-        if (lane == 0) {
-            uint32_t* p = sP + br * 8 + 2 * w;
-            p[0] = rloA; p[1] = rhiA; p[4] = rloB; p[5] = rhiB;
+    for (int task = tid; task < nbr * 8; task += LF_T) {
+        const uint2* tab = &gc->synw[task >> 3][0][task & 7];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < LF_MAX_DEG; ++j) {
+            const uint2 e = tab[j * 8];
+            const uint32_t w0 = *(lds_u32*)(size_t)(e.x & 0xffffu), w1 = *(lds_u32*)(size_t)(e.x >> 16);
+            acc ^= __builtin_amdgcn_alignbit(w1, w0, e.y);
         }
-        cnt += __popc(rloA) + __popc(rhiA) + __popc(rloB) + __popc(rhiB);
-        const uint32_t selA = lane < 32 ? rloA : rhiA, selB = lane < 32 ? rloB : rhiB;
-        a |= ((selA >> (lane & 31)) & 1u) << br;
-        b |= ((selB >> (lane & 31)) & 1u) << br;
+        sP[task] = acc;
+        cnt += __popc(acc);
     }
-    pA = a; pB = b;
-    return block_sum2(cnt, tid, sRed); /* its barriers also publish sP */
+    cnt = add_reduce32(cnt);
+    const int wave_cnt = __builtin_amdgcn_readlane(cnt, 31) + __builtin_amdgcn_readlane(cnt, 63);
+    const int total = block_sum2(wave_cnt, tid, sRed); /* its barriers also publish sP */
+    if (ROWBITS) {
+        uint32_t a = 0, b = 0;
+        const uint32_t* p = sP + (tid >> 5);
+        const uint32_t sh = (uint32_t)tid & 31u;
+        for (int br = 0; br < nbr; ++br) {
+            a |= ((p[br * 8] >> sh) & 1u) << br;
+            b |= ((p[br * 8 + 4] >> sh) & 1u) << br;
+        }
+        pA = a; pB = b;
+    }
+    return total;
 }
 
 /* ---- cheap "certainly dirty" test for decoders that only need unsat != 0 (DecodeMethod 2: no EF tables, no
@@ -756,6 +772,7 @@ __global__ __launch_bounds__(LF_T, LF_WAVES_PER_SIMD) void lnsfaid_decode_kernel
     /* snapshot of the 32 lanes of this group */
     const int g = cw >> 5, lane_in_group = cw & 31;
     if (tid < LNSFAID_GROUP) sStat[tid] = a.status_cur[g * LNSFAID_GROUP + tid];
+    if (tid == LNSFAID_GROUP) sRed[LF_ZERO_SLOT] = 0; /* the word unused synw slots point at */
     __syncthreads();
     int kmax = 0, all_same = 1;
     for (int l = 0; l < LNSFAID_GROUP; ++l) {
@@ -844,7 +861,7 @@ __global__ __launch_bounds__(LF_T, LF_WAVES_PER_SIMD) void lnsfaid_decode_kernel
                 const bool needs_checksums = (METHOD != 2) && (max_iter - prog <= f->floor_iter_thresh);
                 if (needs_checksums || !layer0_dirty(c, sEn, tid, vff0, sRed)) {
                     build_plane<false>(c, sEn, sHard, 0, tid);
-                    const int unsat = syndrome(c, a.code, sHard, sP, tid, pA, pB, sRed);
+                    const int unsat = syndrome<true>(c, a.code, sP, tid, pA, pB, sRed);
                     if (unsat == 0 && prog >= kmax) break; /* clean on the group's front: park */
                     if (LF_OMS(METHOD)) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
                     else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
@@ -852,7 +869,7 @@ __global__ __launch_bounds__(LF_T, LF_WAVES_PER_SIMD) void lnsfaid_decode_kernel
                 main_step<METHOD, UNIW>(c, f, a.code, sEn, g_rows, tid, prog, pA, pB, lme);
                 prog++;
             } else {
-                const int unsat = syndrome(c, a.code, sHard, sP, tid, pA, pB, sRed);
+                const int unsat = syndrome<false>(c, a.code, sP, tid, pA, pB, sRed);
                 if (unsat == 0 && prog >= kmax) break;
                 if (METHOD == 3) bf_step_plain(c, f, a.code, sHard, sHard2 + nw /* 4 count planes in the dead En */, sP, tid, sRed);
                 else bf_step<METHOD>(c, f, a.code, sHard, sHard0, sHard2, sP, tid, ls, sRed);
