@@ -63,6 +63,29 @@ void CLDPC::FakeEncoder(const int* CodeWord_sym)
     }
 }
 
+void CLDPC::GenMsgSeq()
+{
+    for (size_t i = 0; i < (size_t)m_groups * m_frame * m_K; ++i) inputBits[i] = (int8_t)(rand() % 2);
+}
+
+const CEncoder& CLDPC::Encoder()
+{
+    if (!m_encoder_ready) {
+        std::vector<int> row_deg;
+        for (int k = 0; k < NB_DEGRES; ++k) row_deg.insert(row_deg.end(), (size_t)m_deg_rows[k], m_deg[k]);
+        if (!m_encoder.Initial(m_N, m_M, row_deg.data(), PosNoeudsVariable)) die("Encode: the parity part of H is singular", LNSFAID_E_CODE);
+        m_encoder_ready = true;
+    }
+    return m_encoder;
+}
+
+void CLDPC::Encode()
+{
+    const CEncoder& enc = Encoder();
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int g = 0; g < m_groups; ++g) enc.Encode32(inputBits + (size_t)g * 32 * m_K, outputBits + (size_t)g * 32 * m_N);
+}
+
 void CLDPC::float2LimitChar_4bit(int8_t* output, const float* input, float scale, size_t length)
 {
     /* reference CLDPC.cpp:4553-4573: float multiply, truncate toward zero, saturating packs, clamp to +-7 */

@@ -14,6 +14,7 @@
 #include <cstdint>
 
 #include "./Constants/Constants_SSE.h" /* generated: same macros and PosNoeudsVariable as the reference's header */
+#include "CEncoder.h"
 #include "CTool.h"
 #include "lnsfaid.h"
 
@@ -42,6 +43,9 @@ public:
     /* reference CLDPC::Initial(nb_frame, MaxIteration) plus the batch size and the GPU to use */
     void Initial(int nb_frame, int MaxItertion, int groups = 1, int device = 0);
     void FakeEncoder(const int* CodeWord_sym = nullptr); /* nullptr = the shipped all-zero CodeWord_sym */
+    void GenMsgSeq();  /* reference CLDPC.cpp:60-66: inputBits[i] = rand() % 2 */
+    void Encode();     /* reference CLDPC.cpp:68-155, with the generator derived from the code table (CEncoder.h) */
+    const CEncoder& Encoder(); /* derived on first use (about a second) */
     void float2LimitChar_4bit(int8_t* output, const float* input, float scale, size_t length);
 
     void Decode();           /* DecodeMethod 0 and the switch default: normalised min-sum (reference CLDPC.cpp:214) */
@@ -77,5 +81,7 @@ private:
     lnsfaid_group_stats* m_stats;
     int m_device, m_factor_1, m_factor_2;
     bool m_device_io;
+    CEncoder m_encoder;
+    bool m_encoder_ready = false;
 };
 #endif

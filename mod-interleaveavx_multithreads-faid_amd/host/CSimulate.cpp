@@ -68,30 +68,40 @@ void CSimulate::Run()
     static const float table_qpsk[2] = { -0.707107f, 0.707107f }; /* reference CModulate.cpp:4 */
     static const float table_16qam[4] = { -0.316228f, -0.948683f, 0.316228f, 0.948683f }; /* reference CModulate.cpp:5 */
     const int N = ldpc->m_N, K = ldpc->m_K, M = ldpc->m_M;
-    ldpc->FakeEncoder(); /* FAKE_ENCODE path (reference CSimulate.cpp:103-104): GenMatrix is not shipped */
-    /* interleave (identity for InterleaveModType 1) + modulate once, reference CSimulate.cpp:111-116.
+    /* FAKE_ENCODE (the reference's default, CSimulate.cpp:103-104: GenMatrix is not shipped) or, with --encode, random
+     * information bits through the encoder derived from the code table (reference #else branch :106-107) */
+    if (encode) { ldpc->GenMsgSeq(); ldpc->Encode(); }
+    else ldpc->FakeEncoder();
+    /* interleave (identity for InterleaveModType 1) + modulate once per 50 calls, reference CSimulate.cpp:111-116.
      * outputBits of a group is [32][K] then [32][M]; frame m's bit k sits at m*N + k after
-     * BeforeModulationInterleaver (CModulate.cpp:95-148). */
-    const int8_t* ob = ldpc->outputBits;
-    auto tx_bit = [&](int m, int k) { return k < K ? ob[(size_t)m * K + k] : ob[(size_t)32 * K + (size_t)m * M + (k - K)]; };
+     * BeforeModulationInterleaver (CModulate.cpp:95-148).  With FakeEncoder every stream sends the same 32 frames:
+     * one modulated sequence serves all of them. */
     const size_t bits = (size_t)32 * N;
-    if (ModulationType == 1) {
-        BPSKModSeq.resize(bits);
-        for (int m = 0; m < 32; ++m) for (int k = 0; k < N; ++k) BPSKModSeq[(size_t)m * N + k] = 2.0f * tx_bit(m, k) - 1.0f; /* CModulate.cpp:368 */
-    } else if (ModulationType == 2) {
-        ModSeq.resize(bits / 2);
-        for (size_t i = 0; i < bits / 2; ++i) {
-            const size_t b0 = 2 * i, b1 = 2 * i + 1;
-            ModSeq[i].real = table_qpsk[tx_bit((int)(b0 / N), (int)(b0 % N))];
-            ModSeq[i].imag = table_qpsk[tx_bit((int)(b1 / N), (int)(b1 % N))];
-        }
-    } else { /* 16-QAM: I index = 2*b0 + b2, Q index = 2*b1 + b3 (reference CModulate.cpp:253-259, half_sym 2) */
-        ModSeq.resize(bits / 4);
-        for (size_t i = 0; i < bits / 4; ++i) {
-            int b[4];
-            for (int u = 0; u < 4; ++u) { const size_t pos = 4 * i + u; b[u] = tx_bit((int)(pos / N), (int)(pos % N)); }
-            ModSeq[i].real = table_16qam[2 * b[0] + b[2]];
-            ModSeq[i].imag = table_16qam[2 * b[1] + b[3]];
+    const int n_seq = encode ? m_streams : 1;
+    const size_t sym = ModulationType == 1 ? bits : bits / (size_t)ModulationType;
+    if (ModulationType == 1) BPSKModSeq.resize((size_t)n_seq * sym);
+    else ModSeq.resize((size_t)n_seq * sym);
+    for (int g = 0; g < n_seq; ++g) {
+        const int8_t* ob = ldpc->outputBits + (size_t)g * bits;
+        auto tx_bit = [&](int m, int k) { return k < K ? ob[(size_t)m * K + k] : ob[(size_t)32 * K + (size_t)m * M + (k - K)]; };
+        if (ModulationType == 1) {
+            float* dst = BPSKModSeq.data() + (size_t)g * sym;
+            for (int m = 0; m < 32; ++m) for (int k = 0; k < N; ++k) dst[(size_t)m * N + k] = 2.0f * tx_bit(m, k) - 1.0f; /* CModulate.cpp:368 */
+        } else if (ModulationType == 2) {
+            Complex8* dst = ModSeq.data() + (size_t)g * sym;
+            for (size_t i = 0; i < bits / 2; ++i) {
+                const size_t b0 = 2 * i, b1 = 2 * i + 1;
+                dst[i].real = table_qpsk[tx_bit((int)(b0 / N), (int)(b0 % N))];
+                dst[i].imag = table_qpsk[tx_bit((int)(b1 / N), (int)(b1 % N))];
+            }
+        } else { /* 16-QAM: I index = 2*b0 + b2, Q index = 2*b1 + b3 (reference CModulate.cpp:253-259, half_sym 2) */
+            Complex8* dst = ModSeq.data() + (size_t)g * sym;
+            for (size_t i = 0; i < bits / 4; ++i) {
+                int b[4];
+                for (int u = 0; u < 4; ++u) { const size_t pos = 4 * i + u; b[u] = tx_bit((int)(pos / N), (int)(pos % N)); }
+                dst[i].real = table_16qam[2 * b[0] + b[2]];
+                dst[i].imag = table_16qam[2 * b[1] + b[3]];
+            }
         }
     }
     std::vector<float> llr(device_frontend ? 0 : (size_t)m_streams * bits);
@@ -102,6 +112,7 @@ void CSimulate::Run()
         TestFrame += 32ul * m_streams;
         if (device_frontend) {
             if (ModulationType == 1) { fprintf(stderr, "--device-frontend needs modType 2 or 4\n"); exit(EXIT_FAILURE); }
+            if (encode) { fprintf(stderr, "--device-frontend sends the fixed codeword (FakeEncoder); --encode needs the host front-end\n"); exit(EXIT_FAILURE); }
             ldpc->DeviceChannel(decode_method, seeds.data(), m_draws.data(), ModulationType, sigma, scale);
             const uint64_t n = ldpc->DrawsPerGroup(ModulationType);
             for (int s = 0; s < m_streams; ++s) {
@@ -123,13 +134,13 @@ void CSimulate::Run()
             CChannel& ch = channel[s];
             int8_t* fix = ldpc->fixInput + (size_t)s * bits;
             if (ModulationType == 1) {
-                ch.BPSKAWGNChannel(BPSKModSeq.data(), sigma);
+                ch.BPSKAWGNChannel(BPSKModSeq.data() + (encode ? (size_t)s * sym : 0), sigma);
                 for (size_t i = 0; i < bits; ++i) dst[i] = ch.BPSKSymbol[i];
             } else if (ModulationType == 2) {
-                ch.AWGNChannel(ModSeq.data(), (float)(sigma / sqrt(2))); /* reference CSimulate.cpp:126 */
+                ch.AWGNChannel(ModSeq.data() + (encode ? (size_t)s * sym : 0), (float)(sigma / sqrt(2))); /* reference CSimulate.cpp:126 */
                 for (size_t i = 0; i < bits / 2; ++i) { dst[2 * i] = ch.SymbolSeq[i].real; dst[2 * i + 1] = ch.SymbolSeq[i].imag; } /* Demodulation, CModulate.cpp:276-281 */
             } else {
-                ch.AWGNChannel(ModSeq.data(), (float)(sigma / sqrt(2)));
+                ch.AWGNChannel(ModSeq.data() + (encode ? (size_t)s * sym : 0), (float)(sigma / sqrt(2)));
                 for (size_t i = 0; i < bits / 4; ++i) { /* max-log demapper, reference CModulate.cpp:283-293 */
                     dst[4 * i] = ch.SymbolSeq[i].real;
                     dst[4 * i + 1] = ch.SymbolSeq[i].imag;

@@ -25,6 +25,7 @@ public:
     int decode_method = 0, ModulationType = 2, InterleaveModType = 1;
     double decode_seconds = 0; /* host wall time spent inside Decode_*() */
     bool device_frontend = false; /* generate the channel output on the GPU (lnsfaid_frontend_device) */
+    bool encode = false;          /* GenMsgSeq + Encode instead of FakeEncoder (reference FAKE_ENCODE 0) */
     unsigned long sum_iterations = 0, sum_bf_iterations = 0, decoded_groups = 0;
 
     ~CSimulate();

@@ -31,8 +31,11 @@ int main(int argc, char** argv)
     /* OpenMP workers must sleep, not spin, between the channel loops: a spinning pool starves the HIP runtime's
      * threads while the GPU decodes (set before the OpenMP runtime starts) */
     setenv("OMP_WAIT_POLICY", "passive", 0);
+    /* a container usually sees every core of the host but owns a share of them: an OpenMP team as large as the machine
+     * turns every parallel region into time-slicing.  16 workers unless OMP_NUM_THREADS says otherwise. */
+    setenv("OMP_NUM_THREADS", "16", 0);
     int streams = 64, gpus = 1, max_rounds = 0;
-    bool device_frontend = false, force_collect = false;
+    bool device_frontend = false, force_collect = false, encode = false;
     const char* profile = "Profile.txt";
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--streams") && i + 1 < argc) streams = atoi(argv[++i]);
@@ -40,8 +43,9 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--profile") && i + 1 < argc) profile = argv[++i];
         else if (!strcmp(argv[i], "--max-rounds") && i + 1 < argc) max_rounds = atoi(argv[++i]); /* 0 = reference stop rule only */
         else if (!strcmp(argv[i], "--device-frontend")) device_frontend = true; /* channel + demapper + quantiser on the GPU */
+        else if (!strcmp(argv[i], "--encode")) encode = true; /* random information bits + the encoder derived from H (reference FAKE_ENCODE 0) */
         else if (!strcmp(argv[i], "--collect")) force_collect = true; /* collectflag = 1 from the first call (reference: once FER < 1e-5) */
-        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R] [--device-frontend] [--collect]\n", argv[0]); return 2; }
+        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R] [--device-frontend] [--encode] [--collect]\n", argv[0]); return 2; }
     }
     if (streams < 1 || gpus < 1 || gpus > streams) { fprintf(stderr, "need 1 <= gpus <= streams\n"); return 2; }
 
@@ -56,6 +60,7 @@ int main(int argc, char** argv)
     for (int g = 0; g < gpus; ++g) {
         const int first = (int)((long)streams * g / gpus), last = (int)((long)streams * (g + 1) / gpus);
         simulate[g].device_frontend = device_frontend;
+        simulate[g].encode = encode;
         simulate[g].Initial(p_simulation, first, last - first, g);
     }
 

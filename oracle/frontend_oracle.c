@@ -68,8 +68,25 @@ static int8_t quantise_4bit(float x, float scale)
     return (int8_t)q;
 }
 
+/* QPSK with 32 different frames ([32][n_var] bits, frame-major): what the driver sends with a real encoder
+ * (reference CSimulate.cpp:106-107).  frame_stride = 0 repeats one codeword (FakeEncoder). */
+static void qpsk_group(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* bits, int frame_stride, float sigma,
+                       float scale, int8_t* fixInput);
+
+void lnsfaid_frontend_qpsk_frames(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* frames, float sigma,
+                                  float scale, int8_t* fixInput)
+{
+    qpsk_group(fe, n_var, n_check, frames, n_var, sigma, scale, fixInput);
+}
+
 void lnsfaid_frontend_qpsk_group(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* codeword, float sigma,
                                  float scale, int8_t* fixInput)
+{
+    qpsk_group(fe, n_var, n_check, codeword, 0, sigma, scale, fixInput);
+}
+
+static void qpsk_group(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* codeword, int frame_stride, float sigma,
+                       float scale, int8_t* fixInput)
 {
     static const float table_qpsk[2] = { -0.707107f, 0.707107f }; /* CModulate.cpp:4 */
     const int K = n_var - n_check;
@@ -80,7 +97,7 @@ void lnsfaid_frontend_qpsk_group(lnsfaid_frontend* fe, int n_var, int n_check, c
      * (CModulate.cpp:253-259 with half_sym = 1); AWGNChannel draws real then imag (CChannel.cpp:94-95). */
     for (int m = 0; m < 32; ++m)
         for (int k = 0; k < n_var; ++k) {
-            int bit = codeword ? codeword[k] : 0;
+            int bit = codeword ? codeword[(size_t)m * frame_stride + k] : 0;
             float rx = random_norm(sigma_ch, fe) + table_qpsk[bit];
             int8_t q = quantise_4bit(rx, scale);
             if (k < K) fixInput[(size_t)m * K + k] = q;

@@ -45,6 +45,9 @@ void lnsfaid_frontend_qpsk_group(lnsfaid_frontend* fe, int n_var, int n_check, c
                                  float scale, int8_t* fixInput);
 
 /* the same loop body for 16-QAM, modType 4 (table_16qam CModulate.cpp:5, demapper CModulate.cpp:283-293) */
+/* same with 32 different frames, frames = [32][n_var] bits */
+void lnsfaid_frontend_qpsk_frames(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* frames, float sigma,
+                                  float scale, int8_t* fixInput);
 void lnsfaid_frontend_qam16_group(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* codeword, float sigma,
                                   float scale, int8_t* fixInput);
 

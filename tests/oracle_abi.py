@@ -38,6 +38,7 @@ _SYMS = {
     "lnsfaid_frontend_seed": (None, [C.POINTER(Frontend), C.c_int]),
     "lnsfaid_frontend_sigma": (C.c_float, [C.c_float, C.c_int, C.c_double]),
     "lnsfaid_frontend_qpsk_group": (None, [C.POINTER(Frontend), C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
+    "lnsfaid_frontend_qpsk_frames": (None, [C.POINTER(Frontend), C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     "lnsfaid_frontend_qam16_group": (None, [C.POINTER(Frontend), C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
 }
 
@@ -112,11 +113,19 @@ class ReferenceChannel:
         self.mod_type = mod_type  # 2 QPSK, 4 16-QAM (Profile.txt modType)
         self.lib.lnsfaid_frontend_seed(C.byref(self.fe), seed)
 
-    def groups(self, eb_n0_db, n_groups, codeword=None):
+    def groups(self, eb_n0_db, n_groups, codeword=None, frames=None):
+        """codeword: one [N] codeword sent in every frame (FakeEncoder); frames: [32, N] bits, 32 different frames sent in
+        every group (the driver with a real encoder: encoded once per 50 calls, reference CSimulate.cpp:103-116)."""
         N, M = self.code50.N, self.code50.M
         sigma = self.lib.lnsfaid_frontend_sigma(eb_n0_db, self.mod_type, self.RATE)
         gen = {2: self.lib.lnsfaid_frontend_qpsk_group, 4: self.lib.lnsfaid_frontend_qam16_group}[self.mod_type]
         out = np.empty((n_groups, 32 * N), dtype=np.int8)
+        if frames is not None:
+            assert self.mod_type == 2
+            frames = np.ascontiguousarray(frames, dtype=np.int8).reshape(32, N)
+            for g in range(n_groups):
+                self.lib.lnsfaid_frontend_qpsk_frames(C.byref(self.fe), N, M, frames.ctypes.data, sigma, self.scale, out[g].ctypes.data)
+            return out.reshape(-1)
         cw = None
         if codeword is not None:
             codeword = np.ascontiguousarray(codeword, dtype=np.int8)

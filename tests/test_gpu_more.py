@@ -273,6 +273,46 @@ def test_host_driver_result_files(abi, code50, tmp_path, extra):
     assert [int(x) for x in fl[0][len("ErrorChar=["):-2].split()] == want.tolist()
 
 
+def test_host_driver_with_encoder(abi, code50, encoder, tmp_path):
+    """N2: `lnsfaid_sim --encode` sends random information bits (libc rand() % 2, reference CLDPC.cpp:60-66) through the
+    systematic encoder the driver derives from the code table (host/CEncoder.cpp; the reference's GenMatrix is not shipped).
+    Rebuilt here with glibc's rand(), the test encoder (tests/gf2_encoder.py) and the restated channel: the counters
+    must match the oracle's, and every sent frame must be a codeword."""
+    import ctypes
+    exe = os.path.join(oa.PKG_DIR, "host", "lnsfaid_sim")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(oa.PKG_DIR, "host")])
+    eb_n0 = 3.55
+    prof = open(os.path.join(oa.PKG_DIR, "host", "Profile.txt")).read()
+    prof = prof.replace("StartSNR: 3.3", "StartSNR: %g" % eb_n0).replace("EndSNR: 3.85", "EndSNR: %g" % (eb_n0 + 0.05))
+    (tmp_path / "Profile.txt").write_text(prof)
+    res = subprocess.run([exe, "--streams", "2", "--gpus", "1", "--max-rounds", "1", "--encode", "--collect"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    row = [l for l in res.stdout.splitlines() if re.match(r"\s*%g\s" % eb_n0, l)][-1].split()
+    got = [int(row[1]), int(row[2]), int(row[3]), int(row[6])]
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)  # a fresh process starts from seed 1; the driver never calls srand (nor does the reference)
+    K, N = code50.K, code50.N
+    info = np.array([libc.rand() % 2 for _ in range(2 * 32 * K)], dtype=np.uint8).reshape(2, 32, K)
+    cfg = abi.default_cfg(2, 10)
+    want = [0, 0, 0, 0]
+    sent = []
+    for s, seed in enumerate([101, 103]):
+        frames = encoder.encode(info[s])
+        sent.append(frames)
+        fix = oa.ReferenceChannel(code50, seed, 13.0).groups(eb_n0, 50, frames=frames)
+        dec, _ = oa.decode_mt(code50, cfg, fix, 50, kind="avx2")
+        c = oa.Oracle(code50, cfg).count_errors(dec, np.ascontiguousarray(np.tile(info[s].reshape(-1).astype(np.int8), 50)), 50)
+        want = [w + x for w, x in zip(want, c)]
+    assert got == want, (got, want, res.stdout)
+    assert want[1] > 0  # the point has frame errors, so the dumps below exist
+    # the frames the driver sent (outputbits of the dump) are the encoder's, i.e. codewords of H
+    ob = [l for l in (tmp_path / "errordecode.txt").read_text().splitlines() if l.startswith("outputbits=[")]
+    first = np.array([int(x) for x in ob[0][len("outputbits=["):-2].split()], dtype=np.int8)
+    assert any(np.array_equal(first, f) for f in np.concatenate(sent))
+
+
 def _derived_code(abi, lib, drop_cols, from_block_row):
     """A second quasi-cyclic code for the generic code paths: the 50G-PON table with the circulants of the
     block columns `drop_cols` removed from block rows >= from_block_row (degree 23 -> 23 - len(drop_cols))."""
