@@ -416,3 +416,23 @@ def test_random_codewords(abi, code50, encoder, method, eb_n0):
     assert np.array_equal(out, ref) and np.array_equal(st, rst)
     assert cnt == oa.Oracle(code50, cfg).count_errors(ref, inp, ng)
     assert cnt[1] < ng * 32  # not everything fails: the words really are codewords
+
+
+@pytest.mark.parametrize("eb_n0", [3.2, 3.6, 4.0])
+@pytest.mark.parametrize("method", [2, 5, 1, 0, 4, 3])
+def test_soak_against_cpu_port(abi, code50, method, eb_n0):
+    """32 768 frames per case (1024 groups, several dispatch rounds of workgroups) against the vectorised CPU port, every
+    frame and every per-group iteration count: the place where rare message patterns (ties, zero messages on the argmin
+    edge, saturated rows) turn up."""
+    ng = 1024
+    cfg = abi.default_cfg(method, 10)
+    if method == 0:
+        cfg.factor_1, cfg.factor_2 = 24, 26  # the shipped Profile.txt factors are OMS offsets; 0.75 / 0.81 normalisation
+    fix = oa.synth_llr(ng, code50.N, eb_n0, seed=1000 + 17 * method + int(eb_n0 * 10))
+    d = abi.Decoder(code50, cfg, 0, ng)
+    out, st = d.decode(fix, ng)
+    d.close()
+    ref, ref_st = oa.decode_mt(code50, cfg, fix, ng, kind="avx2")
+    bad = np.nonzero((out != ref).reshape(ng * 32, code50.N).any(axis=1))[0]
+    assert bad.size == 0, "frames differ from the CPU port: %s" % bad[:16].tolist()
+    assert np.array_equal(st, ref_st)
