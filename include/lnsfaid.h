@@ -187,6 +187,13 @@ uint64_t lnsfaid_frontend_draws_per_group(const lnsfaid_ctx* ctx, int32_t mod_ty
  * device allocator (host/CLDPC.cpp) runs front-end -> decode -> counters on them with the *_device entry points. */
 int lnsfaid_io_buffers(lnsfaid_ctx* ctx, int8_t** d_fixInput, int8_t** d_decodedBits, lnsfaid_group_stats** d_stats);
 
+/* Page-lock / release a host buffer (hipHostRegister / hipHostUnregister) for callers that have no HIP toolchain of
+ * their own: with fixInput and decodedBits both pinned, lnsfaid_decode overlaps its copies with the decode (pieces of
+ * whole groups on separate streams); pageable buffers are copied, decoded and copied back in sequence.  Unregister before
+ * the buffer is freed. */
+int lnsfaid_host_register(void* ptr, size_t bytes);
+int lnsfaid_host_unregister(void* ptr);
+
 /* Copy the per-group iteration counts a *_device decode left in the context's statistics buffer (the d_stats of
  * lnsfaid_io_buffers) to the host: what Decode_OMSBF / Decode_OMS_DTBF return as BFiter (reference CLDPC.h:150-151,
  * histogrammed into iterCount.txt by CSimulate.cpp:148-178) when the decoded frames themselves stay on the device. */

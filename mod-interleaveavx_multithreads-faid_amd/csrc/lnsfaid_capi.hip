@@ -37,6 +37,8 @@ static int hip_fail(hipError_t e, const char* what)
         if (e_ != hipSuccess) return hip_fail(e_, #call);  \
     } while (0)
 
+#define LF_IO_CHUNKS 8 /* pieces the host-pointer path is cut into when both host buffers are pinned */
+
 struct lnsfaid_ctx {
     int device = 0;
     size_t max_groups = 0;
@@ -46,6 +48,8 @@ struct lnsfaid_ctx {
     size_t lds_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t s_in = nullptr, s_out = nullptr; /* copy streams of the pipelined host-pointer path */
+    hipEvent_t ev_in[LF_IO_CHUNKS] = {};
     LfDevCode* d_code = nullptr;
     LfDevCfg* d_cfg = nullptr;
     int8_t* d_en = nullptr;
@@ -98,7 +102,6 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
         const int deg = row_deg[(size_t)br * Z];
         out->deg[br] = deg;
         const uint16_t* row0 = code->pos_vn + e;
-        for (int j = 0; j < 32; ++j) out->syn[br][j] = 0xffffffffu;
         for (int j = 0; j < 64; ++j) out->sbtab[br][j] = 0u;
         int prev_cb = -1;
         for (int j = 0; j < deg; ++j) {
@@ -106,7 +109,6 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
             if (row0[j] >= N || cb <= prev_cb) return LNSFAID_E_CODE; /* ascending, no block column twice */
             prev_cb = cb;
             out->circ[br][j].sb = (uint32_t)cb * (uint32_t)Z + (uint32_t)sh;
-            out->syn[br][j] = (uint32_t)sh | ((uint32_t)cb << 8);
             out->sbtab[br][LF_JCODE_A(j)] = out->sbtab[br][LF_JCODE_B(j)] = out->circ[br][j].sb;
             if (out->col_weight[cb] >= LF_MAX_COLW) return LNSFAID_E_CODE;
             out->colcirc[cb][out->col_weight[cb]++] = (uint32_t)br | ((uint32_t)sh << 8);
@@ -222,6 +224,9 @@ extern "C" void lnsfaid_destroy(lnsfaid_ctx* ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
+    if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
+    for (auto e : ctx->ev_in) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -374,6 +379,13 @@ extern "C" int lnsfaid_read_stats(lnsfaid_ctx* ctx, lnsfaid_group_stats* stats, 
     return LNSFAID_OK;
 }
 
+static bool host_pinned(const void* p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; } /* plain malloc memory */
+    return at.type == hipMemoryTypeHost;
+}
+
 extern "C" int lnsfaid_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, size_t n_groups, int8_t* decodedBits,
                               lnsfaid_group_stats* stats)
 {
@@ -383,15 +395,59 @@ extern "C" int lnsfaid_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, size_t n
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_io(ctx);
     if (rc) return rc;
-    const size_t bytes = n_groups * LNSFAID_GROUP * (size_t)ctx->n_var;
-    HIP_TRY(hipMemcpyAsync(ctx->d_io_in, fixInput, bytes, hipMemcpyHostToDevice, ctx->stream));
-    rc = lnsfaid_decode_device(ctx, ctx->d_io_in, n_groups, ctx->d_io_out, ctx->d_io_stats);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(decodedBits, ctx->d_io_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t group_bytes = LNSFAID_GROUP * (size_t)ctx->n_var;
+    const size_t bytes = n_groups * group_bytes;
+    /* Pinned host buffers (hipHostMalloc / lnsfaid_host_register): cut the batch into pieces of whole groups and overlap
+     * the copy-in of piece c + 1 and the copy-out of piece c - 1 with the decode of piece c (groups are independent, and
+     * a piece is decoded to completion before the next one starts, so the pieces share the per-codeword state buffers).
+     * Pageable buffers cannot overlap (the runtime stages them synchronously): one copy in, one decode, one copy out. */
+    size_t chunk = ((n_groups + LF_IO_CHUNKS - 1) / LF_IO_CHUNKS + 63) / 64 * 64; /* >= one full wave of workgroups */
+    if (!host_pinned(fixInput) || !host_pinned(decodedBits) || chunk >= n_groups) {
+        HIP_TRY(hipMemcpyAsync(ctx->d_io_in, fixInput, bytes, hipMemcpyHostToDevice, ctx->stream));
+        rc = lnsfaid_decode_device(ctx, ctx->d_io_in, n_groups, ctx->d_io_out, ctx->d_io_stats);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(decodedBits, ctx->d_io_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        if (!ctx->s_in) {
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking));
+            for (auto& e : ctx->ev_in) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        const size_t n_chunks = (n_groups + chunk - 1) / chunk; /* <= LF_IO_CHUNKS */
+        for (size_t c = 0; c < n_chunks; ++c) { /* all copies in are queued at once, one event per piece */
+            const size_t g0 = c * chunk, ng = g0 + chunk <= n_groups ? chunk : n_groups - g0;
+            HIP_TRY(hipMemcpyAsync(ctx->d_io_in + g0 * group_bytes, fixInput + g0 * group_bytes, ng * group_bytes, hipMemcpyHostToDevice, ctx->s_in));
+            HIP_TRY(hipEventRecord(ctx->ev_in[c], ctx->s_in));
+        }
+        for (size_t c = 0; c < n_chunks; ++c) {
+            const size_t g0 = c * chunk, ng = g0 + chunk <= n_groups ? chunk : n_groups - g0;
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_in[c], 0));
+            rc = lnsfaid_decode_device(ctx, ctx->d_io_in + g0 * group_bytes, ng, ctx->d_io_out + g0 * group_bytes, ctx->d_io_stats + g0);
+            if (rc) { (void)hipStreamSynchronize(ctx->s_in); (void)hipStreamSynchronize(ctx->s_out); return rc; }
+            /* decode_device returns with the piece finished: its copy out needs no further ordering */
+            HIP_TRY(hipMemcpyAsync(decodedBits + g0 * group_bytes, ctx->d_io_out + g0 * group_bytes, ng * group_bytes, hipMemcpyDeviceToHost, ctx->s_out));
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->s_out));
+    }
     if (stats)
         HIP_TRY(hipMemcpyAsync(stats, ctx->d_io_stats, n_groups * sizeof(lnsfaid_group_stats), hipMemcpyDeviceToHost,
                                ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LNSFAID_OK;
+}
+
+/* ---- pinned host memory for callers without a HIP toolchain (the reference is plain C++) ---------------- */
+extern "C" int lnsfaid_host_register(void* ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return LNSFAID_E_INVAL;
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable)); /* valid on every device of the process */
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_host_unregister(void* ptr)
+{
+    if (!ptr) return LNSFAID_E_INVAL;
+    HIP_TRY(hipHostUnregister(ptr));
     return LNSFAID_OK;
 }
 

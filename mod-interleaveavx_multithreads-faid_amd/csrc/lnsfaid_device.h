@@ -30,7 +30,7 @@ struct LfCirc {
 };
 
 /* Quasi-cyclic view of the reference's PosNoeudsVariable table.  Uniformly indexed fields are read with
- * scalar loads (constant address space), lane-indexed ones (syn, colcirc, wcol) with vector loads. */
+ * scalar loads (constant address space), lane-indexed ones (sbtab, synw, colcirc, wcol) with vector loads. */
 struct LfDevCode {
     int32_t n_var, n_check, k_info, nbr, nbc, puncture_tail, n_words /* n_var / 32 */, p_words /* n_check / 32 */;
     int32_t n_wcols;                          /* block columns whose weight equals REGULAR_COL_WEIGHT           */
@@ -40,7 +40,6 @@ struct LfDevCode {
     uint2 synw[LF_MAX_BR][LF_MAX_DEG][8];     /* syndrome walk, per (layer, circulant, 32-row word k): .x = LDS byte addresses of
                                                * the two hard-plane words holding bits (32k + shift) mod 256 ... + 31 of the block
                                                * column (low / high 16 bits), .y = bit offset; unused slots: the zero word, 0     */
-    uint32_t syn[LF_MAX_BR][32];              /* lane j: shift | block column << 8 of circulant j, ~0u beyond deg */
     int32_t col_weight[LF_MAX_BC];
     int32_t wcol[LF_MAX_BC];                  /* the n_wcols block columns of weight W                           */
     uint32_t colcirc[LF_MAX_BC][LF_MAX_COLW]; /* block row | shift << 8 for every circulant of the column         */

@@ -25,6 +25,8 @@ CLDPC::CLDPC()
 CLDPC::~CLDPC()
 {
     for (auto& c : m_ctx) lnsfaid_destroy(c);
+    if (fixInput) (void)lnsfaid_host_unregister(fixInput);       /* harmless error when it was never registered */
+    if (decodedBits) (void)lnsfaid_host_unregister(decodedBits);
     free(inputBits); free(outputBits); free(decodedBits); free(fixInput); free(m_stats);
 }
 
@@ -41,6 +43,8 @@ void CLDPC::Initial(int nb_frame, int MaxItertion, int groups, int device)
     fixInput = (int8_t*)calloc(frames * m_N, 1);
     m_stats = (lnsfaid_group_stats*)calloc(groups, sizeof(lnsfaid_group_stats));
     if (!inputBits || !outputBits || !decodedBits || !fixInput || !m_stats) die("allocation", LNSFAID_E_NOMEM);
+    /* page-locked transfer buffers: lnsfaid_decode then overlaps its copies with the decode */
+    m_pinned = lnsfaid_host_register(fixInput, frames * m_N) == LNSFAID_OK && lnsfaid_host_register(decodedBits, frames * m_N) == LNSFAID_OK;
     /* the code definition comes from the Constants_SSE.h-format header, exactly as in the reference */
     static const int32_t deg[] = { DEG_1, DEG_2, DEG_3 };
     static const int32_t rows[] = { DEG_1_COMPUTATIONS, DEG_2_COMPUTATIONS, DEG_3_COMPUTATIONS };

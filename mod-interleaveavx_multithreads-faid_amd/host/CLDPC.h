@@ -81,6 +81,7 @@ private:
     lnsfaid_group_stats* m_stats;
     int m_device, m_factor_1, m_factor_2;
     bool m_device_io;
+    bool m_pinned = false;
     CEncoder m_encoder;
     bool m_encoder_ready = false;
 };

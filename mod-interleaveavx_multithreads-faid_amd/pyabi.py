@@ -70,6 +70,8 @@ SYMBOLS = {
     "lnsfaid_frontend_draws_per_group": (C.c_uint64, [C.c_void_p, C.c_int32]),
     "lnsfaid_io_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "lnsfaid_read_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "lnsfaid_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "lnsfaid_host_unregister": (C.c_int, [C.c_void_p]),
     "lnsfaid_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32]),
     "lnsfaid_stream": (C.c_void_p, [C.c_void_p]),
     "lnsfaid_strerror": (C.c_char_p, [C.c_int]),

@@ -436,3 +436,24 @@ def test_soak_against_cpu_port(abi, code50, method, eb_n0):
     bad = np.nonzero((out != ref).reshape(ng * 32, code50.N).any(axis=1))[0]
     assert bad.size == 0, "frames differ from the CPU port: %s" % bad[:16].tolist()
     assert np.array_equal(st, ref_st)
+
+
+def test_pinned_host_buffers_take_the_pipelined_path(abi, lib, code50):
+    """lnsfaid_decode with page-locked host buffers (lnsfaid_host_register) cuts the batch into pieces of whole groups and
+    overlaps copies and decode; results and per-group statistics must equal the single-piece path, also when the last
+    piece is ragged."""
+    ng = 200  # pieces of 64 groups: 64 + 64 + 64 + 8
+    cfg = abi.default_cfg(2, 10)
+    fix = oa.synth_llr(ng, code50.N, 3.6, seed=77)
+    d = abi.Decoder(code50, cfg, 0, ng)
+    ref, ref_st = d.decode(fix, ng)  # pageable numpy buffers
+    src, dst = fix.copy(), np.zeros_like(fix)
+    st = np.zeros((ng, 2), dtype=np.int32)
+    assert lib.lnsfaid_host_register(src.ctypes.data, src.size) == 0 and lib.lnsfaid_host_register(dst.ctypes.data, dst.size) == 0
+    try:
+        assert lib.lnsfaid_decode(d.ctx, src.ctypes.data, ng, dst.ctypes.data, st.ctypes.data) == 0
+    finally:
+        assert lib.lnsfaid_host_unregister(src.ctypes.data) == 0 and lib.lnsfaid_host_unregister(dst.ctypes.data) == 0
+    d.close()
+    assert np.array_equal(dst, ref) and np.array_equal(st, ref_st)
+    assert lib.lnsfaid_host_register(None, 16) != 0
