@@ -2,26 +2,26 @@
 
 #include <cmath>
 
+/* One step of the three Wichmann-Hill style congruential generators and their combined fractional part
+ * (reference CChannel.cpp:71-80).  Everything after the integer update is float arithmetic, summed left to right. */
 float CChannel::Random_Uniform(RandSeed& rs)
 {
-    /* reference CChannel.cpp:71-80 (float arithmetic) */
-    float temp = 0.0;
-    rs.IX = (rs.IX * 249) % 61967;
-    rs.IY = (rs.IY * 251) % 63443;
-    rs.IZ = (rs.IZ * 252) % 63599;
-    temp = (((float)rs.IX) / ((float)61967)) + (((float)rs.IY) / ((float)63443)) + (((float)rs.IZ) / ((float)63599));
-    temp -= (int)temp;
-    return temp;
+    static const unsigned long mul[3] = { 249, 251, 252 }, mod[3] = { 61967, 63443, 63599 };
+    unsigned long* x[3] = { &rs.IX, &rs.IY, &rs.IZ };
+    float sum = 0.0f;
+    for (int g = 0; g < 3; ++g) {
+        *x[g] = (*x[g] * mul[g]) % mod[g];
+        sum = g == 0 ? (float)*x[g] / (float)mod[g] : sum + (float)*x[g] / (float)mod[g];
+    }
+    return sum - (float)(int)sum;
 }
 
+/* Box-Muller on two successive uniforms, evaluated in double and rounded to float once (reference CChannel.cpp:82-89) */
 float CChannel::Random_Norm(double sigma, RandSeed& rs)
 {
-    /* reference CChannel.cpp:82-89 (double arithmetic, float result) */
-    float u1, u2, u;
-    u1 = Random_Uniform(rs);
-    u2 = Random_Uniform(rs);
-    u = sigma * cos(2 * 3.1415926535897932384626433832795 * u2) * sqrt(-2.0 * log(1.0 - u1));
-    return u;
+    const float first = Random_Uniform(rs), second = Random_Uniform(rs);
+    const double two_pi = 2 * 3.1415926535897932384626433832795;
+    return (float)(sigma * cos(two_pi * second) * sqrt(-2.0 * log(1.0 - first)));
 }
 
 void CChannel::AWGNChannel(const Complex8* in, float sigma)

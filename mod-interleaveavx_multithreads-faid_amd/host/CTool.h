@@ -10,20 +10,14 @@
 #define REGULAR_COL_WEIGHT 3 /* reference CTool.h:6 */
 
 struct Parameter_Simulation {
-    float snr_start; /* StartSNR */
-    float snr_pass;  /* SNRPass  */
-    float snr_end;   /* EndSNR   */
-    float scale;     /* scale: quantiser scale */
-    int decode_method; /* DecodeMethod: 1 OMS, 2 FAID+DTBF, 3 OMS+BF, 4 OMS+DTBF, 5 FAID+2B1C (reference README.md:13) */
-    int Max_Iteration; /* MaxIteration */
-    int mod_type;      /* modType: 1 BPSK, 2 QPSK */
-    int interleavemod_type; /* InterleaveModType */
-    int Factor_1;
-    int Factor_2;
-    int nb_frames;     /* noFrames: 32 */
+    /* Profile.txt keys in file order: StartSNR, SNRPass, EndSNR, scale (quantiser), DecodeMethod (0 NMS, 1 OMS, 2 FAID + DTBF,
+     * 3 OMS + BF, 4 OMS + DTBF, 5 FAID + 2B1C; reference README.md:13), MaxIteration, modType (1 BPSK, 2 QPSK, 4 16-QAM),
+     * InterleaveModType, Factor_1, Factor_2, noFrames (32), code file name, Z (circulant size), ce (collect errors) */
+    float snr_start = 0, snr_pass = 0, snr_end = 0, scale = 0;
+    int decode_method = 0, Max_Iteration = 0, mod_type = 0, interleavemod_type = 0;
+    int Factor_1 = 0, Factor_2 = 0, nb_frames = 0;
     std::string fileName;
-    int Z;
-    int ce;
+    int Z = 0, ce = 0;
 };
 
 /* Reads ./Profile.txt (or `path`).  Returns false instead of the reference's getchar()+exit() so that the
