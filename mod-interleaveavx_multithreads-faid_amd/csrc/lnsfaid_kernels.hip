@@ -155,36 +155,40 @@ __device__ __forceinline__ void window64(const uint32_t* blk, uint32_t o, uint32
 
 /* ---- bit plane from En: hard decision En > 0 (CDecoder_FAID.cpp:299, :6416-6419), or with CONF the 2B1C
  * confidence bit |En| >= thr (CDecoder_FAID_2B1C.cpp:6132-6136) ----------------------------------------- */
+/* Four variable nodes per lane: one ds_read_b32, a byte-parallel sign test, the four flags gathered into a nibble
+ * (v_dot4 with weights 1, 2, 4, 8) and the nibbles of eight neighbouring lanes OR-ed into one plane word with three DPP
+ * row shifts.  N must be a multiple of 4; thr <= 31 (|En| <= 31). */
 template <bool CONF>
 __device__ void build_plane(CCode c, const int8_t* sEn, uint32_t* plane, int thr, int tid)
 {
+    typedef const __attribute__((address_space(3))) uint32_t lds_u32;
     const int N = c->n_var;
-    constexpr int U = 8; /* LDS reads in flight per thread: the loop is a chain of LDS round trips otherwise */
-    int base = 0;
-    for (; base + U * LF_T <= N; base += U * LF_T) {
-        int e[U];
+    const uint32_t lane = (uint32_t)tid & 63u, sh = 4u * (lane & 7u);
+    const int th = thr < 1 ? 1 : (thr > 32 ? 32 : thr); /* |En| <= 31: every threshold above 31 means "never" */
+    const uint32_t thr4 = (uint32_t)th * 0x01010101u, thm4 = (uint32_t)(th - 1) * 0x01010101u;
+    constexpr int U = 4; /* LDS reads in flight per thread */
+    for (int base = 0; base < N; base += U * 4 * LF_T) {
+        uint32_t x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) e[u] = en_ld((uint32_t)(base + u * LF_T + tid));
-        unsigned long long h[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) h[u] = CONF ? __ballot(e[u] >= thr || e[u] <= -thr) : __ballot(e[u] > 0);
-        if ((tid & 63) == 0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int w = (base + u * LF_T + tid) >> 5;
-                plane[w] = (uint32_t)h[u];
-                plane[w + 1] = (uint32_t)(h[u] >> 32);
-            }
+        for (int u = 0; u < U; ++u) {
+            const int v = base + u * 4 * LF_T + 4 * tid;
+            x[u] = v < N ? *(lds_u32*)(size_t)(uint32_t)v : 0u;
         }
-    }
-    for (; base < N; base += LF_T) {
-        const int v = base + tid;
-        const int e = en_ld((uint32_t)v);
-        const unsigned long long h = CONF ? __ballot(e >= thr || e <= -thr) : __ballot(e > 0);
-        if ((tid & 63) == 0) {
-            const int w = v >> 5;
-            plane[w] = (uint32_t)h;
-            plane[w + 1] = (uint32_t)(h >> 32);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = base + u * 4 * LF_T + 4 * tid;
+            uint32_t p;
+            if (CONF) { /* |En| >= thr on the biased bytes En + 128: no carries between bytes for |En|, thr <= 31 */
+                const uint32_t y = x[u] ^ 0x80808080u;
+                p = thr < 1 ? 0x80808080u : ((y - thr4) | ~(y + thm4)) & 0x80808080u;
+            } else {    /* En > 0: sign clear and low seven bits not all zero */
+                p = ((x[u] & 0x7f7f7f7fu) + 0x7f7f7f7fu) & ~x[u] & 0x80808080u;
+            }
+            uint32_t w = __builtin_amdgcn_udot4(p >> 7, 0x08040201u, 0u, false) << sh;
+            w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x111, 0xf, 0xf, true); /* row_shr:1 */
+            w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x112, 0xf, 0xf, true); /* row_shr:2 */
+            w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x114, 0xf, 0xf, true); /* row_shr:4 */
+            if ((lane & 7u) == 7u && v < N) plane[v >> 5] = w; /* v = 4 * (lane of the word's last nibble): v >> 5 is the word */
         }
     }
     __syncthreads();

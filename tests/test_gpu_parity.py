@@ -104,3 +104,18 @@ def test_oms_offset_corner_factors(abi, code50, method, f1, f2):
     out, stats = dec.decode(fix, 2)
     dec.close()
     assert np.array_equal(out, ref) and np.array_equal(stats, ref_stats)
+
+
+@pytest.mark.parametrize("thr", [13, 1, 0, 7, 31, 32, 100])
+def test_2b1c_confidence_threshold(abi, code50, thr):
+    """hard2 = |En| >= threshold (reference CDecoder_FAID_2B1C.cpp:6130-6134, shipped value 13): the byte-parallel plane
+    build must agree for every threshold, including "always" (<= 0) and "never" (> 31)."""
+    cfg = abi.default_cfg(5, 10)
+    cfg.hard2_threshold = thr
+    fix = oa.ReferenceChannel(code50, 167, 13.0).groups(3.5, 3)
+    ref, ref_stats = oa.Oracle(code50, cfg).decode(fix, 3)
+    dec = abi.Decoder(code50, cfg, device=0, max_groups=3)
+    out, stats = dec.decode(fix, 3)
+    dec.close()
+    assert np.array_equal(out, ref) and np.array_equal(stats, ref_stats)
+    assert stats[:, 1].max() > 0  # the bit-flipping stage (the only user of hard2) ran
