@@ -182,6 +182,16 @@ int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, const uint6
                             int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput);
 uint64_t lnsfaid_frontend_draws_per_group(const lnsfaid_ctx* ctx, int32_t mod_type);
 
+/* Frames for lnsfaid_frontend_device when every stream sends its own 32 frames (the reference with a real encoder:
+ * GenMsgSeq + Encode once per 50 calls, CSimulate.cpp:106-116) instead of one codeword in every frame.
+ *   outputBits  host, n_streams groups in CLDPC::Encode's output layout ([32][K] then [32][M] per group)
+ *   inputBits   host, their information bits [n_streams][32][K] (what CalculateErrors compares with)
+ * Both are copied to the device and used by every following lnsfaid_frontend_device call that passes codeword = NULL and
+ * at most n_streams streams; outputBits = NULL switches back.  lnsfaid_frontend_input_bits returns the device copy of
+ * inputBits for lnsfaid_count_errors_device (NULL while no frames are set). */
+int lnsfaid_frontend_set_frames(lnsfaid_ctx* ctx, const int8_t* outputBits, const int8_t* inputBits, size_t n_streams);
+int lnsfaid_frontend_input_bits(lnsfaid_ctx* ctx, const int8_t** d_inputBits);
+
 /* The context's own device staging buffers (each max_groups * 32 * n_var bytes): the fixInput buffer the
  * host-pointer entry points copy into and the decodedBits buffer they copy out of.  A host driver without its own
  * device allocator (host/CLDPC.cpp) runs front-end -> decode -> counters on them with the *_device entry points. */

@@ -21,8 +21,8 @@ extern "C" hipError_t lf_launch_count_errors(const int8_t* decoded, const int8_t
                                              size_t n_cw, unsigned long long* out, hipStream_t stream);
 
 extern "C" hipError_t lf_launch_frontend(const uint32_t* d_seeds, const unsigned long long* d_draws, int n_streams, int mod_type,
-                                         float sigma_ch, float scale, const int8_t* d_codeword, int n_var, int n_check,
-                                         int8_t* d_fix, hipStream_t stream);
+                                         float sigma_ch, float scale, const int8_t* d_codeword, const int8_t* d_frames, int n_var,
+                                         int n_check, int8_t* d_fix, hipStream_t stream);
 
 static thread_local char g_hip_err[256] = "";
 
@@ -71,6 +71,9 @@ struct lnsfaid_ctx {
     uint32_t* d_fe_seeds = nullptr;
     unsigned long long* d_fe_draws = nullptr;
     int8_t* d_fe_codeword = nullptr;
+    int8_t* d_fe_frames = nullptr; /* per-stream sent frames (lnsfaid_frontend_set_frames), encoder output layout */
+    int8_t* d_fe_input = nullptr;  /* their information bits, [stream][32][K] */
+    size_t fe_frames_streams = 0;  /* 0: frames not in use */
 };
 
 /* ---- code analysis: PosNoeudsVariable -> circulants ------------------------------------------------- */
@@ -219,6 +222,7 @@ extern "C" void lnsfaid_destroy(lnsfaid_ctx* ctx)
     (void)hipFree(ctx->d_remaining); (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_io_in); (void)hipFree(ctx->d_io_out); (void)hipFree(ctx->d_io_stats);
     (void)hipFree(ctx->d_fe_seeds); (void)hipFree(ctx->d_fe_draws); (void)hipFree(ctx->d_fe_codeword);
+    (void)hipFree(ctx->d_fe_frames); (void)hipFree(ctx->d_fe_input);
     if (ctx->h_remaining) (void)hipHostFree(ctx->h_remaining);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -352,6 +356,30 @@ static int ensure_io(lnsfaid_ctx* ctx)
     HIP_TRY(hipMalloc(&ctx->d_io_in, bytes));
     HIP_TRY(hipMalloc(&ctx->d_io_out, bytes));
     HIP_TRY(hipMalloc(&ctx->d_io_stats, ctx->max_groups * sizeof(lnsfaid_group_stats)));
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_frontend_set_frames(lnsfaid_ctx* ctx, const int8_t* outputBits, const int8_t* inputBits, size_t n_streams)
+{
+    if (!ctx || n_streams > ctx->max_groups) return LNSFAID_E_INVAL;
+    if (!outputBits || n_streams == 0) { ctx->fe_frames_streams = 0; return LNSFAID_OK; } /* back to one codeword for all */
+    if (!inputBits) return LNSFAID_E_INVAL;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->d_fe_frames) {
+        HIP_TRY(hipMalloc(&ctx->d_fe_frames, ctx->max_groups * LNSFAID_GROUP * (size_t)ctx->n_var));
+        HIP_TRY(hipMalloc(&ctx->d_fe_input, ctx->max_groups * LNSFAID_GROUP * (size_t)ctx->k_info));
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->d_fe_frames, outputBits, n_streams * LNSFAID_GROUP * (size_t)ctx->n_var, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_fe_input, inputBits, n_streams * LNSFAID_GROUP * (size_t)ctx->k_info, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->fe_frames_streams = n_streams;
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_frontend_input_bits(lnsfaid_ctx* ctx, const int8_t** d_inputBits)
+{
+    if (!ctx || !d_inputBits) return LNSFAID_E_INVAL;
+    *d_inputBits = ctx->fe_frames_streams ? ctx->d_fe_input : nullptr;
     return LNSFAID_OK;
 }
 
@@ -513,7 +541,9 @@ extern "C" int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, 
     /* AWGNChannel(ModSeq, sigma / sqrt(2)): float / double -> double, narrowed to float (CSimulate.cpp:126) */
     const float sigma_ch = (float)((double)sigma / 1.4142135623730951);
     HIP_TRY(lf_launch_frontend(ctx->d_fe_seeds, ctx->d_fe_draws, (int)n_streams, mod_type, sigma_ch, scale,
-                               codeword ? ctx->d_fe_codeword : nullptr, ctx->n_var, ctx->n_check, d_fixInput, ctx->stream));
+                               codeword ? ctx->d_fe_codeword : nullptr,
+                               (!codeword && ctx->fe_frames_streams >= n_streams) ? ctx->d_fe_frames : nullptr, ctx->n_var,
+                               ctx->n_check, d_fixInput, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream)); /* seeds / draws_before may be reused by the caller */
     return LNSFAID_OK;
 }

@@ -73,7 +73,8 @@ __device__ __forceinline__ size_t fix_pos(long pos, int n_var, int k_info, int n
 __global__ __launch_bounds__(256) void lnsfaid_frontend_kernel(const uint32_t* __restrict__ seeds,
                                                                const unsigned long long* __restrict__ draws_before, int mod_type,
                                                                float sigma_ch, float scale, const int8_t* __restrict__ codeword,
-                                                               int n_var, int n_check, int8_t* __restrict__ fix_input)
+                                                               const int8_t* __restrict__ frames, int n_var, int n_check,
+                                                               int8_t* __restrict__ fix_input)
 {
     const int stream = (int)blockIdx.y;
     const long bits = 32L * n_var;
@@ -82,6 +83,13 @@ __global__ __launch_bounds__(256) void lnsfaid_frontend_kernel(const uint32_t* _
     if (first >= symbols) return;
     const int k_info = n_var - n_check;
     int8_t* out = fix_input + (size_t)stream * (size_t)bits;
+    /* sent bit at position pos of the stream: its own 32 frames (encoder output layout = the fixInput layout), or one
+     * codeword repeated in every frame (FakeEncoder), or all-zero */
+    const int8_t* fr = frames ? frames + (size_t)stream * (size_t)bits : nullptr;
+    auto tx = [&](long pos) -> int {
+        if (fr) return fr[fix_pos(pos, n_var, k_info, n_check)];
+        return codeword ? codeword[pos % n_var] : 0;
+    };
     /* symbol i uses normals 2i and 2i+1, normal k uses uniforms 2k+1 and 2k+2 of the stream */
     const unsigned long long skip = draws_before[stream] + 4ull * (unsigned long long)first;
     const uint32_t seed = seeds[stream];
@@ -93,14 +101,14 @@ __global__ __launch_bounds__(256) void lnsfaid_frontend_kernel(const uint32_t* _
     const long last = first + FE_RUN < symbols ? first + FE_RUN : symbols;
     for (long i = first; i < last; ++i) {
         if (mod_type == 2) {
-            const int b0 = codeword ? codeword[(2 * i) % n_var] : 0, b1 = codeword ? codeword[(2 * i + 1) % n_var] : 0;
+            const int b0 = tx(2 * i), b1 = tx(2 * i + 1);
             const float re = wh_norm(sigma, s) + (b0 ? 0.707107f : -0.707107f);
             const float im = wh_norm(sigma, s) + (b1 ? 0.707107f : -0.707107f);
             out[fix_pos(2 * i, n_var, k_info, n_check)] = quantise_4bit(re, scale);
             out[fix_pos(2 * i + 1, n_var, k_info, n_check)] = quantise_4bit(im, scale);
         } else {
             int b[4];
-            for (int u = 0; u < 4; ++u) b[u] = codeword ? codeword[(4 * i + u) % n_var] : 0;
+            for (int u = 0; u < 4; ++u) b[u] = tx(4 * i + u);
             const float t16[4] = { -0.316228f, -0.948683f, 0.316228f, 0.948683f };
             const float re = wh_norm(sigma, s) + t16[2 * b[0] + b[2]];
             const float im = wh_norm(sigma, s) + t16[2 * b[1] + b[3]];
@@ -114,12 +122,12 @@ __global__ __launch_bounds__(256) void lnsfaid_frontend_kernel(const uint32_t* _
 }
 
 extern "C" hipError_t lf_launch_frontend(const uint32_t* d_seeds, const unsigned long long* d_draws, int n_streams, int mod_type,
-                                         float sigma_ch, float scale, const int8_t* d_codeword, int n_var, int n_check,
-                                         int8_t* d_fix, hipStream_t stream)
+                                         float sigma_ch, float scale, const int8_t* d_codeword, const int8_t* d_frames, int n_var,
+                                         int n_check, int8_t* d_fix, hipStream_t stream)
 {
     const long symbols = 32L * n_var / mod_type;
     const unsigned bx = (unsigned)((symbols + 256L * FE_RUN - 1) / (256L * FE_RUN));
     hipLaunchKernelGGL(lnsfaid_frontend_kernel, dim3(bx, (unsigned)n_streams), dim3(256), 0, stream, d_seeds, d_draws, mod_type,
-                       sigma_ch, scale, d_codeword, n_var, n_check, d_fix);
+                       sigma_ch, scale, d_codeword, d_frames, n_var, n_check, d_fix);
     return hipGetLastError();
 }

@@ -135,6 +135,14 @@ void CLDPC::decode_with(int method)
     if (rc) die("lnsfaid_decode", rc);
 }
 
+void CLDPC::DeviceFrames(int decode_method, bool per_stream_frames)
+{
+    lnsfaid_ctx* ctx = context(decode_method);
+    const int rc = per_stream_frames ? lnsfaid_frontend_set_frames(ctx, outputBits, inputBits, (size_t)m_groups)
+                                     : lnsfaid_frontend_set_frames(ctx, nullptr, nullptr, 0);
+    if (rc) die("lnsfaid_frontend_set_frames", rc);
+}
+
 void CLDPC::DeviceChannel(int decode_method, const uint32_t* seeds, const uint64_t* draws_before, int mod_type, float sigma,
                           float scale)
 {
@@ -227,7 +235,9 @@ Statistic CLDPC::CalculateErrors()
     if (m_device_io) {
         int8_t* d_out = nullptr;
         rc = lnsfaid_io_buffers(ctx, nullptr, &d_out, nullptr);
-        if (!rc) rc = lnsfaid_count_errors_device(ctx, d_out, nullptr /* all-zero codeword */, (size_t)m_groups, out);
+        const int8_t* d_in = nullptr; /* NULL = all-zero codeword; the sent information bits when frames are set */
+        if (!rc) rc = lnsfaid_frontend_input_bits(ctx, &d_in);
+        if (!rc) rc = lnsfaid_count_errors_device(ctx, d_out, d_in, (size_t)m_groups, out);
     } else {
         rc = lnsfaid_count_errors(ctx, decodedBits, inputBits, (size_t)m_groups, out);
     }

@@ -61,8 +61,11 @@ public:
 
     /* Device-resident mode (--device-frontend): the channel output of `m_groups` reference worker threads is
      * generated on the GPU straight into the decoder's input buffer, Decode_*() and CalculateErrors() then work on
-     * device buffers and fixInput / decodedBits on the host are not touched.  All-zero codeword only (FakeEncoder
-     * with the shipped CodeWord_sym). */
+     * device buffers and fixInput / decodedBits on the host are not touched.  Sends the all-zero codeword (FakeEncoder
+     * with the shipped CodeWord_sym) unless DeviceFrames() installed the encoder's output. */
+    /* with per_stream_frames the device front-end sends outputBits (after Encode) instead of the all-zero codeword and
+     * CalculateErrors compares with inputBits */
+    void DeviceFrames(int decode_method, bool per_stream_frames);
     void DeviceChannel(int decode_method, const uint32_t* seeds, const uint64_t* draws_before, int mod_type, float sigma,
                        float scale);
     uint64_t DrawsPerGroup(int mod_type);

@@ -104,6 +104,7 @@ void CSimulate::Run()
             }
         }
     }
+    if (device_frontend) ldpc->DeviceFrames(decode_method, encode); /* the 32 frames of every stream, once per 50 calls */
     std::vector<float> llr(device_frontend ? 0 : (size_t)m_streams * bits);
     std::vector<int> BFiters_((size_t)m_streams * 51, 0); /* per stream, reference CSimulate.cpp:99 */
     std::vector<uint32_t> seeds(m_streams);
@@ -112,7 +113,7 @@ void CSimulate::Run()
         TestFrame += 32ul * m_streams;
         if (device_frontend) {
             if (ModulationType == 1) { fprintf(stderr, "--device-frontend needs modType 2 or 4\n"); exit(EXIT_FAILURE); }
-            if (encode) { fprintf(stderr, "--device-frontend sends the fixed codeword (FakeEncoder); --encode needs the host front-end\n"); exit(EXIT_FAILURE); }
+
             ldpc->DeviceChannel(decode_method, seeds.data(), m_draws.data(), ModulationType, sigma, scale);
             const uint64_t n = ldpc->DrawsPerGroup(ModulationType);
             for (int s = 0; s < m_streams; ++s) {

@@ -273,7 +273,8 @@ def test_host_driver_result_files(abi, code50, tmp_path, extra):
     assert [int(x) for x in fl[0][len("ErrorChar=["):-2].split()] == want.tolist()
 
 
-def test_host_driver_with_encoder(abi, code50, encoder, tmp_path):
+@pytest.mark.parametrize("extra", [[], ["--device-frontend"]], ids=["host_frontend", "device_frontend"])
+def test_host_driver_with_encoder(abi, code50, encoder, tmp_path, extra):
     """N2: `lnsfaid_sim --encode` sends random information bits (libc rand() % 2, reference CLDPC.cpp:60-66) through the
     systematic encoder the driver derives from the code table (host/CEncoder.cpp; the reference's GenMatrix is not shipped).
     Rebuilt here with glibc's rand(), the test encoder (tests/gf2_encoder.py) and the restated channel: the counters
@@ -286,7 +287,7 @@ def test_host_driver_with_encoder(abi, code50, encoder, tmp_path):
     prof = open(os.path.join(oa.PKG_DIR, "host", "Profile.txt")).read()
     prof = prof.replace("StartSNR: 3.3", "StartSNR: %g" % eb_n0).replace("EndSNR: 3.85", "EndSNR: %g" % (eb_n0 + 0.05))
     (tmp_path / "Profile.txt").write_text(prof)
-    res = subprocess.run([exe, "--streams", "2", "--gpus", "1", "--max-rounds", "1", "--encode", "--collect"], cwd=tmp_path,
+    res = subprocess.run([exe, "--streams", "2", "--gpus", "1", "--max-rounds", "1", "--encode", "--collect"] + extra, cwd=tmp_path,
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr
     row = [l for l in res.stdout.splitlines() if re.match(r"\s*%g\s" % eb_n0, l)][-1].split()
@@ -307,6 +308,8 @@ def test_host_driver_with_encoder(abi, code50, encoder, tmp_path):
         want = [w + x for w, x in zip(want, c)]
     assert got == want, (got, want, res.stdout)
     assert want[1] > 0  # the point has frame errors, so the dumps below exist
+    if extra:  # lnsfaid_frontend_set_frames: the GPU sent the same frames (the counters above prove it); no dumps in this mode
+        return
     # the frames the driver sent (outputbits of the dump) are the encoder's, i.e. codewords of H
     ob = [l for l in (tmp_path / "errordecode.txt").read_text().splitlines() if l.startswith("outputbits=[")]
     first = np.array([int(x) for x in ob[0][len("outputbits=["):-2].split()], dtype=np.int8)
