@@ -253,19 +253,24 @@ __device__ int syndrome(CCode c, const LfDevCode* gc, uint32_t* sP, int tid, uin
  * syndrome are only built when layer 0 is clean.  Returns a workgroup-uniform flag. */
 __device__ bool layer0_dirty(CCode c, const int8_t* sEn, int tid, uint32_t vff, int* sRed)
 {
-    const int deg = c->deg[0];
-    int accA = 0, accB = 0;
+    /* Half of the layer's rows (those of wave 0: 0..63 and 128..191) prove "dirty" just as well in all but a vanishing
+     * share of the cases, where the full syndrome decides as it would have anyway; the other wave only joins the barrier. */
+    int dirty = 0;
+    if (tid < 64) {
+        const int deg = c->deg[0];
+        int accA = 0, accB = 0;
 #pragma unroll
-    for (int j = 0; j < LF_MAX_DEG; ++j) {
-        if (j < deg) {
-            const uint32_t sb = c->circ[0][j].sb;
-            const uint32_t ad = vn_offset((uint32_t)tid, sb, vff);
-            accA ^= -en_ld(ad);
-            accB ^= -en_ld(ad ^ 128u);
+        for (int j = 0; j < LF_MAX_DEG; ++j) {
+            if (j < deg) {
+                const uint32_t sb = c->circ[0][j].sb;
+                const uint32_t ad = vn_offset((uint32_t)tid, sb, vff);
+                accA ^= -en_ld(ad);
+                accB ^= -en_ld(ad ^ 128u);
+            }
         }
+        dirty = __ballot((accA | accB) < 0) != 0ull ? 1 : 0;
     }
-    const unsigned long long d = __ballot((accA | accB) < 0);
-    return block_sum2(d != 0ull ? 1 : 0, tid, sRed) != 0;
+    return block_sum2(dirty, tid, sRed) != 0;
 }
 
 /* selective offset of OMS_MODE 1 on one minimum (CDecoder_OMS.cpp:388-425); all operands are int8 in the
