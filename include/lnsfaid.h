@@ -113,6 +113,13 @@ int lnsfaid_code_50gpon(lnsfaid_code* code, uint16_t* pos_vn, int32_t* deg3, int
 /* Fill `cfg` with the reference's shipped constants for DecodeMethod 0..5. */
 int lnsfaid_cfg_default(lnsfaid_cfg* cfg, int32_t decode_method, int32_t max_iteration);
 
+/* Replace cfg->v2c_map by one of the table sets the reference selects at compile time in CDecoder_FAID.cpp
+ * (#define FAID3 - the shipped default -, FAID32 or FAID2, CDecoder_FAID.cpp:8, :12-127). */
+#define LNSFAID_TABLES_FAID3 0
+#define LNSFAID_TABLES_FAID32 1
+#define LNSFAID_TABLES_FAID2 2
+int lnsfaid_cfg_table_preset(lnsfaid_cfg* cfg, int32_t preset);
+
 /* ---- decoder context --------------------------------------------------------- */
 
 /* Replaces CLDPC::Initial (CLDPC.cpp:4772-4817): validates the code (must be

@@ -66,6 +66,29 @@ static void fill_map(int8_t dst[4][8], const int8_t row[8])
     for (int w = 0; w < 4; ++w) memcpy(dst[w], row, 8);
 }
 
+/* The reference's other compile-time table sets of Decode_FAID (#define FAID32 / FAID2 instead of FAID3,
+ * CDecoder_FAID.cpp:8, :51-127); every weight class carries the same row in all of them. */
+int lnsfaid_cfg_table_preset(lnsfaid_cfg* cfg, int32_t preset)
+{
+    static const int8_t faid3[6][8] = { /* CDecoder_FAID.cpp:13-48 */
+        { 0, 1, 1, 2, 3, 3, 3, 3 }, { 0, 1, 1, 2, 3, 3, 3, 3 }, { 0, 1, 1, 2, 4, 4, 4, 4 },
+        { 0, 1, 1, 3, 3, 4, 4, 4 }, { 0, 1, 1, 3, 3, 3, 6, 6 }, { 0, 1, 1, 3, 3, 3, 7, 7 },
+    };
+    static const int8_t faid32[6][8] = { /* CDecoder_FAID.cpp:52-87 */
+        { 0, 1, 1, 2, 3, 3, 3, 3 }, { 0, 1, 1, 2, 3, 3, 3, 3 }, { 0, 1, 1, 2, 4, 4, 4, 4 },
+        { 1, 1, 1, 1, 4, 4, 4, 4 }, { 1, 1, 1, 1, 5, 5, 5, 5 }, { 1, 1, 1, 1, 6, 6, 6, 6 },
+    };
+    static const int8_t faid2[6][8] = { /* CDecoder_FAID.cpp:91-126 */
+        { 0, 0, 2, 2, 2, 2, 2, 2 }, { 0, 0, 2, 2, 2, 2, 2, 2 }, { 1, 1, 1, 3, 3, 3, 3, 3 },
+        { 1, 1, 1, 4, 4, 4, 4, 4 }, { 1, 1, 1, 5, 5, 5, 5, 5 }, { 1, 1, 1, 6, 6, 6, 6, 6 },
+    };
+    const int8_t (*t)[8] = preset == LNSFAID_TABLES_FAID3 ? faid3 : preset == LNSFAID_TABLES_FAID32 ? faid32
+                         : preset == LNSFAID_TABLES_FAID2 ? faid2 : 0;
+    if (!cfg || !t) return LNSFAID_E_INVAL;
+    for (int it = 0; it < 6; ++it) fill_map(cfg->v2c_map[it], t[it]);
+    return LNSFAID_OK;
+}
+
 int lnsfaid_cfg_default(lnsfaid_cfg* cfg, int32_t decode_method, int32_t max_iteration)
 {
     /* every weight class (3, 6, 11, other) carries the same row in the shipped tables */

@@ -62,7 +62,7 @@ def _set_tables(cfg, rows, ef_rows=None):
                     cfg.v2c_map_ef[it][w][a] = ef_rows[it][a]
 
 
-@pytest.mark.parametrize("name", ["faid32", "identity", "steep", "not_monotone", "zero_heavy"])
+@pytest.mark.parametrize("name", ["faid32", "faid2", "identity", "steep", "not_monotone", "zero_heavy"])
 @pytest.mark.parametrize("method", [2, 5])
 def test_uniform_table_variants(abi, code50, method, name):
     """Table sets other than the shipped one, identical for the four weight classes.  Non-decreasing sets take the kernel's
@@ -71,6 +71,8 @@ def test_uniform_table_variants(abi, code50, method, name):
     tables = {
         "faid32": [[0, 1, 1, 2, 3, 3, 3, 3], [0, 1, 1, 2, 3, 3, 3, 3], [0, 1, 1, 2, 4, 4, 4, 4],
                    [1, 1, 1, 1, 4, 4, 4, 4], [1, 1, 1, 1, 5, 5, 5, 5], [1, 1, 1, 1, 6, 6, 6, 6]],  # CDecoder_FAID.cpp:51-88
+        "faid2": [[0, 0, 2, 2, 2, 2, 2, 2], [0, 0, 2, 2, 2, 2, 2, 2], [1, 1, 1, 3, 3, 3, 3, 3],
+                  [1, 1, 1, 4, 4, 4, 4, 4], [1, 1, 1, 5, 5, 5, 5, 5], [1, 1, 1, 6, 6, 6, 6, 6]],  # CDecoder_FAID.cpp:91-126
         "identity": [[0, 1, 2, 3, 4, 5, 6, 7]] * 6,
         "steep": [[0, 0, 0, 7, 7, 7, 7, 7], [0, 0, 5, 5, 5, 7, 7, 7], [0, 3, 3, 3, 6, 6, 7, 7]] * 2,
         "not_monotone": [[0, 2, 1, 3, 3, 3, 7, 7], [0, 1, 1, 2, 3, 3, 3, 3], [1, 0, 1, 2, 4, 4, 4, 4]] * 2,

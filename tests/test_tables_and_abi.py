@@ -99,3 +99,23 @@ def test_create_rejects_bad_arguments_without_touching_a_gpu(abi, lib, code50):
     cfg.v2c_map[0][0][0] = 9  # outside the 3-bit alphabet
     assert lib.lnsfaid_create(C.byref(ctx), C.byref(code50.code), C.byref(cfg), 0, 1) == -1
     assert not ctx.value
+
+
+def test_table_presets_match_the_reference_text(abi, lib):
+    """FAID3 / FAID32 / FAID2 of CDecoder_FAID.cpp:12-127: the 'weight = 3' rows as printed there (all four rows of a
+    table are equal in the reference)."""
+    want = {
+        0: [[0, 1, 1, 2, 3, 3, 3, 3], [0, 1, 1, 2, 3, 3, 3, 3], [0, 1, 1, 2, 4, 4, 4, 4],
+            [0, 1, 1, 3, 3, 4, 4, 4], [0, 1, 1, 3, 3, 3, 6, 6], [0, 1, 1, 3, 3, 3, 7, 7]],
+        1: [[0, 1, 1, 2, 3, 3, 3, 3], [0, 1, 1, 2, 3, 3, 3, 3], [0, 1, 1, 2, 4, 4, 4, 4],
+            [1, 1, 1, 1, 4, 4, 4, 4], [1, 1, 1, 1, 5, 5, 5, 5], [1, 1, 1, 1, 6, 6, 6, 6]],
+        2: [[0, 0, 2, 2, 2, 2, 2, 2], [0, 0, 2, 2, 2, 2, 2, 2], [1, 1, 1, 3, 3, 3, 3, 3],
+            [1, 1, 1, 4, 4, 4, 4, 4], [1, 1, 1, 5, 5, 5, 5, 5], [1, 1, 1, 6, 6, 6, 6, 6]],
+    }
+    for preset, rows in want.items():
+        c = abi.default_cfg(2, 10, lib)
+        assert lib.lnsfaid_cfg_table_preset(C.byref(c), preset) == 0
+        for it in range(6):
+            for w in range(4):
+                assert list(c.v2c_map[it][w]) == rows[it]
+    assert lib.lnsfaid_cfg_table_preset(C.byref(c), 3) != 0
