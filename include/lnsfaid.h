@@ -178,7 +178,7 @@ int lnsfaid_count_errors_device(lnsfaid_ctx* ctx, const int8_t* d_decodedBits,
  *   CLDPC::float2LimitChar_4bit (CLDPC.cpp:4553-4573).
  *   seeds[s]        RandomSeed of stream s (IX = IY = IZ = seed, CChannel.cpp:121)
  *   draws_before[s] uniforms stream s has consumed so far; one group consumes lnsfaid_frontend_draws_per_group()
- *   mod_type        Profile.txt modType: 2 (QPSK) or 4 (16-QAM); InterleaveModType 1
+ *   mod_type        Profile.txt modType: 2 (QPSK), 4, 6, 8 (16-, 64-, 256-QAM); InterleaveModType: lnsfaid_frontend_set_interleave
  *   sigma           CSimulate::Configure's sigma (CSimulate.cpp:69-74); the channel adds N(0, (sigma/sqrt 2)^2) per axis
  *   codeword        host, [n_var] bits 0/1 sent in every frame (FakeEncoder), NULL = all-zero
  *   d_fixInput      device, n_streams groups in the decoder's layout
@@ -188,6 +188,11 @@ int lnsfaid_count_errors_device(lnsfaid_ctx* ctx, const int8_t* d_decodedBits,
 int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, const uint64_t* draws_before, size_t n_streams,
                             int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput);
 uint64_t lnsfaid_frontend_draws_per_group(const lnsfaid_ctx* ctx, int32_t mod_type);
+
+/* Profile.txt InterleaveModType for lnsfaid_frontend_device: the block interleaver of BeforeModulationInterleaver /
+ * AfterDeModulationDeInterleaver (CModulate.cpp:95-212) inside every frame; 1 (the default and the shipped value) is the
+ * identity.  Must divide n_var. */
+int lnsfaid_frontend_set_interleave(lnsfaid_ctx* ctx, int32_t interleave_mod_type);
 
 /* Frames for lnsfaid_frontend_device when every stream sends its own 32 frames (the reference with a real encoder:
  * GenMsgSeq + Encode once per 50 calls, CSimulate.cpp:106-116) instead of one codeword in every frame.

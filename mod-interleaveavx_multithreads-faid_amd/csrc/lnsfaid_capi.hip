@@ -22,7 +22,7 @@ extern "C" hipError_t lf_launch_count_errors(const int8_t* decoded, const int8_t
 
 extern "C" hipError_t lf_launch_frontend(const uint32_t* d_seeds, const unsigned long long* d_draws, int n_streams, int mod_type,
                                          float sigma_ch, float scale, const int8_t* d_codeword, const int8_t* d_frames, int n_var,
-                                         int n_check, int8_t* d_fix, hipStream_t stream);
+                                         int n_check, int interleave, int8_t* d_fix, hipStream_t stream);
 
 static thread_local char g_hip_err[256] = "";
 
@@ -74,6 +74,7 @@ struct lnsfaid_ctx {
     int8_t* d_fe_frames = nullptr; /* per-stream sent frames (lnsfaid_frontend_set_frames), encoder output layout */
     int8_t* d_fe_input = nullptr;  /* their information bits, [stream][32][K] */
     size_t fe_frames_streams = 0;  /* 0: frames not in use */
+    int fe_interleave = 1;         /* InterleaveModType of the device front-end */
 };
 
 /* ---- code analysis: PosNoeudsVariable -> circulants ------------------------------------------------- */
@@ -359,6 +360,13 @@ static int ensure_io(lnsfaid_ctx* ctx)
     return LNSFAID_OK;
 }
 
+extern "C" int lnsfaid_frontend_set_interleave(lnsfaid_ctx* ctx, int32_t interleave_mod_type)
+{
+    if (!ctx || interleave_mod_type < 1 || ctx->n_var % interleave_mod_type != 0) return LNSFAID_E_INVAL;
+    ctx->fe_interleave = interleave_mod_type;
+    return LNSFAID_OK;
+}
+
 extern "C" int lnsfaid_frontend_set_frames(lnsfaid_ctx* ctx, const int8_t* outputBits, const int8_t* inputBits, size_t n_streams)
 {
     if (!ctx || n_streams > ctx->max_groups) return LNSFAID_E_INVAL;
@@ -518,7 +526,7 @@ extern "C" int lnsfaid_count_errors(lnsfaid_ctx* ctx, const int8_t* decodedBits,
 /* ---- front-end on the device ------------------------------------------------------------------------ */
 extern "C" uint64_t lnsfaid_frontend_draws_per_group(const lnsfaid_ctx* ctx, int32_t mod_type)
 {
-    if (!ctx || (mod_type != 2 && mod_type != 4)) return 0;
+    if (!ctx || (mod_type != 2 && mod_type != 4 && mod_type != 6 && mod_type != 8)) return 0;
     /* 32 * n_var / mod_type symbols, 2 normals per symbol, 2 uniforms per normal */
     return (uint64_t)32 * (uint64_t)ctx->n_var / (uint64_t)mod_type * 4u;
 }
@@ -526,9 +534,9 @@ extern "C" uint64_t lnsfaid_frontend_draws_per_group(const lnsfaid_ctx* ctx, int
 extern "C" int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, const uint64_t* draws_before, size_t n_streams,
                                        int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput)
 {
-    if (!ctx || !seeds || !draws_before || !d_fixInput || (mod_type != 2 && mod_type != 4)) return LNSFAID_E_INVAL;
+    if (!ctx || !seeds || !draws_before || !d_fixInput || (mod_type != 2 && mod_type != 4 && mod_type != 6 && mod_type != 8)) return LNSFAID_E_INVAL;
     if (n_streams == 0) return LNSFAID_OK;
-    if (n_streams > ctx->max_groups || (32L * ctx->n_var) % (mod_type * 2) != 0) return LNSFAID_E_INVAL;
+    if (n_streams > ctx->max_groups || (32L * ctx->n_var) % mod_type != 0) return LNSFAID_E_INVAL;
     HIP_TRY(hipSetDevice(ctx->device));
     if (!ctx->d_fe_seeds) {
         HIP_TRY(hipMalloc(&ctx->d_fe_seeds, ctx->max_groups * sizeof(uint32_t)));
@@ -543,7 +551,7 @@ extern "C" int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, 
     HIP_TRY(lf_launch_frontend(ctx->d_fe_seeds, ctx->d_fe_draws, (int)n_streams, mod_type, sigma_ch, scale,
                                codeword ? ctx->d_fe_codeword : nullptr,
                                (!codeword && ctx->fe_frames_streams >= n_streams) ? ctx->d_fe_frames : nullptr, ctx->n_var,
-                               ctx->n_check, d_fixInput, ctx->stream));
+                               ctx->n_check, ctx->fe_interleave, d_fixInput, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream)); /* seeds / draws_before may be reused by the caller */
     return LNSFAID_OK;
 }

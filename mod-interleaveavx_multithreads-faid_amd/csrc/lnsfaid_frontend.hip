@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void lnsfaid_frontend_kernel(const uint32_t* _
                                                                const unsigned long long* __restrict__ draws_before, int mod_type,
                                                                float sigma_ch, float scale, const int8_t* __restrict__ codeword,
                                                                const int8_t* __restrict__ frames, int n_var, int n_check,
-                                                               int8_t* __restrict__ fix_input)
+                                                               int interleave, int8_t* __restrict__ fix_input)
 {
     const int stream = (int)blockIdx.y;
     const long bits = 32L * n_var;
@@ -99,35 +99,46 @@ __global__ __launch_bounds__(256) void lnsfaid_frontend_kernel(const uint32_t* _
     s.iz = (uint32_t)(((unsigned long long)(seed % 63599u) * modpow(252u, skip, 63599u)) % 63599u);
     const double sigma = (double)sigma_ch;
     const long last = first + FE_RUN < symbols ? first + FE_RUN : symbols;
+    /* Modulation / Demodulation / (de)interleaver of reference CModulate.cpp:95-362 for QPSK, 16-, 64- and 256-QAM: symbol i
+     * takes stream positions Q i .. Q i + Q - 1, position p of a frame carries code bit (N / I) (p mod I) + p div I. */
+    const float t2[2] = { -0.707107f, 0.707107f };
+    const float t4[4] = { -0.316228f, -0.948683f, 0.316228f, 0.948683f };
+    const float t6[8] = { -0.462910f, -0.154303f, -0.771517f, -1.08012f, 0.462910f, 0.154303f, 0.771517f, 1.08012f };
+    const float t8[16] = { -0.383482f, -0.536875f, -0.230089f, -0.076696f, -0.843661f, -0.690268f, -0.997054f, -1.150447f,
+                           0.383482f, 0.536875f, 0.230089f, 0.076696f, 0.843661f, 0.690268f, 0.997054f, 1.150447f };
+    const double f4[1] = { 0.6324555 }, f6[2] = { 0.6172134, 0.3086067 }, f8[3] = { 0.613568, 0.306784, 0.153392 };
+    const int Q = mod_type, half = Q / 2;
     for (long i = first; i < last; ++i) {
-        if (mod_type == 2) {
-            const int b0 = tx(2 * i), b1 = tx(2 * i + 1);
-            const float re = wh_norm(sigma, s) + (b0 ? 0.707107f : -0.707107f);
-            const float im = wh_norm(sigma, s) + (b1 ? 0.707107f : -0.707107f);
-            out[fix_pos(2 * i, n_var, k_info, n_check)] = quantise_4bit(re, scale);
-            out[fix_pos(2 * i + 1, n_var, k_info, n_check)] = quantise_4bit(im, scale);
-        } else {
-            int b[4];
-            for (int u = 0; u < 4; ++u) b[u] = tx(4 * i + u);
-            const float t16[4] = { -0.316228f, -0.948683f, 0.316228f, 0.948683f };
-            const float re = wh_norm(sigma, s) + t16[2 * b[0] + b[2]];
-            const float im = wh_norm(sigma, s) + t16[2 * b[1] + b[3]];
-            const float l2 = (float)(fabs((double)re) - 0.6324555), l3 = (float)(fabs((double)im) - 0.6324555);
-            out[fix_pos(4 * i, n_var, k_info, n_check)] = quantise_4bit(re, scale);
-            out[fix_pos(4 * i + 1, n_var, k_info, n_check)] = quantise_4bit(im, scale);
-            out[fix_pos(4 * i + 2, n_var, k_info, n_check)] = quantise_4bit(l2, scale);
-            out[fix_pos(4 * i + 3, n_var, k_info, n_check)] = quantise_4bit(l3, scale);
+        int idx_i = 0, idx_q = 0;
+        long cpos[8]; /* frame * n_var + code bit of each position of the symbol */
+        for (int u = 0; u < Q; ++u) {
+            const long pos = (long)Q * i + u;
+            const long m = pos / n_var, p = pos % n_var;
+            cpos[u] = m * n_var + (n_var / interleave) * (p % interleave) + p / interleave;
+            const int b = tx(cpos[u]);
+            if (u & 1) idx_q += b << (half - u / 2 - 1); else idx_i += b << (half - u / 2 - 1);
         }
+        const float ai = Q == 2 ? t2[idx_i] : Q == 4 ? t4[idx_i] : Q == 6 ? t6[idx_i] : t8[idx_i];
+        const float aq = Q == 2 ? t2[idx_q] : Q == 4 ? t4[idx_q] : Q == 6 ? t6[idx_q] : t8[idx_q];
+        float l[8];
+        l[0] = wh_norm(sigma, s) + ai;
+        l[1] = wh_norm(sigma, s) + aq;
+        for (int n = 1; n < half; ++n) {
+            const double c = Q == 4 ? f4[n - 1] : Q == 6 ? f6[n - 1] : f8[n - 1];
+            l[2 * n] = (float)(fabs((double)l[2 * n - 2]) - c);
+            l[2 * n + 1] = (float)(fabs((double)l[2 * n - 1]) - c);
+        }
+        for (int u = 0; u < Q; ++u) out[fix_pos(cpos[u], n_var, k_info, n_check)] = quantise_4bit(l[u], scale);
     }
 }
 
 extern "C" hipError_t lf_launch_frontend(const uint32_t* d_seeds, const unsigned long long* d_draws, int n_streams, int mod_type,
                                          float sigma_ch, float scale, const int8_t* d_codeword, const int8_t* d_frames, int n_var,
-                                         int n_check, int8_t* d_fix, hipStream_t stream)
+                                         int n_check, int interleave, int8_t* d_fix, hipStream_t stream)
 {
     const long symbols = 32L * n_var / mod_type;
     const unsigned bx = (unsigned)((symbols + 256L * FE_RUN - 1) / (256L * FE_RUN));
     hipLaunchKernelGGL(lnsfaid_frontend_kernel, dim3(bx, (unsigned)n_streams), dim3(256), 0, stream, d_seeds, d_draws, mod_type,
-                       sigma_ch, scale, d_codeword, d_frames, n_var, n_check, d_fix);
+                       sigma_ch, scale, d_codeword, d_frames, n_var, n_check, interleave, d_fix);
     return hipGetLastError();
 }

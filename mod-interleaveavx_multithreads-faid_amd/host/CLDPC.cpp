@@ -135,9 +135,10 @@ void CLDPC::decode_with(int method)
     if (rc) die("lnsfaid_decode", rc);
 }
 
-void CLDPC::DeviceFrames(int decode_method, bool per_stream_frames)
+void CLDPC::DeviceFrames(int decode_method, bool per_stream_frames, int interleave_mod_type)
 {
     lnsfaid_ctx* ctx = context(decode_method);
+    if (lnsfaid_frontend_set_interleave(ctx, interleave_mod_type)) die("lnsfaid_frontend_set_interleave", LNSFAID_E_INVAL);
     const int rc = per_stream_frames ? lnsfaid_frontend_set_frames(ctx, outputBits, inputBits, (size_t)m_groups)
                                      : lnsfaid_frontend_set_frames(ctx, nullptr, nullptr, 0);
     if (rc) die("lnsfaid_frontend_set_frames", rc);

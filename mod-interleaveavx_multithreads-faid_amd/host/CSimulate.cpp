@@ -36,8 +36,10 @@ void CSimulate::Initial(Parameter_Simulation& p, int first_index, int streams, i
     m_Z = p.Z > 0 ? p.Z : 256;
     ModulationType = p.mod_type;
     InterleaveModType = p.interleavemod_type;
-    if ((ModulationType != 1 && ModulationType != 2 && ModulationType != 4) || InterleaveModType != 1) {
-        fprintf(stderr, "host front-end supports modType 1 (BPSK) / 2 (QPSK) / 4 (16-QAM) with InterleaveModType 1 only\n");
+    const bool qam = ModulationType == 2 || ModulationType == 4 || ModulationType == 6 || ModulationType == 8;
+    if ((ModulationType != 1 && !qam) || InterleaveModType < 1 || _NoVar % InterleaveModType != 0
+        || (qam && (32L * _NoVar) % ModulationType != 0)) {
+        fprintf(stderr, "front-end: modType 1 (BPSK), 2, 4, 6, 8 (QPSK, 16-, 64-, 256-QAM); InterleaveModType must divide the frame length\n");
         exit(EXIT_FAILURE);
     }
     ldpc = new CLDPC();
@@ -65,14 +67,24 @@ void CSimulate::Configure(float Eb_N0, int _decode_method)
 
 void CSimulate::Run()
 {
-    static const float table_qpsk[2] = { -0.707107f, 0.707107f }; /* reference CModulate.cpp:4 */
-    static const float table_16qam[4] = { -0.316228f, -0.948683f, 0.316228f, 0.948683f }; /* reference CModulate.cpp:5 */
+    /* Gray-mapped amplitude tables per axis and the max-log demapper's fold constants (reference CModulate.cpp:4-7, :273-362) */
+    static const float table_qpsk[2] = { -0.707107f, 0.707107f };
+    static const float table_16qam[4] = { -0.316228f, -0.948683f, 0.316228f, 0.948683f };
+    static const float table_64qam[8] = { -0.462910f, -0.154303f, -0.771517f, -1.08012f, 0.462910f, 0.154303f, 0.771517f, 1.08012f };
+    static const float table_256qam[16] = { -0.383482f, -0.536875f, -0.230089f, -0.076696f, -0.843661f, -0.690268f, -0.997054f, -1.150447f,
+                                            0.383482f, 0.536875f, 0.230089f, 0.076696f, 0.843661f, 0.690268f, 0.997054f, 1.150447f };
+    static const double fold_16[1] = { 0.6324555 }, fold_64[2] = { 0.6172134, 0.3086067 }, fold_256[3] = { 0.613568, 0.306784, 0.153392 };
+    const float* axis = ModulationType == 2 ? table_qpsk : ModulationType == 4 ? table_16qam : ModulationType == 6 ? table_64qam : table_256qam;
+    const double* fold = ModulationType == 4 ? fold_16 : ModulationType == 6 ? fold_64 : fold_256;
     const int N = ldpc->m_N, K = ldpc->m_K, M = ldpc->m_M;
+    const int Q = ModulationType, half = Q / 2, I = InterleaveModType;
+    /* block interleaver inside every frame (reference CModulate.cpp:134-146, :152-166): position p carries code bit k(p) */
+    auto code_bit = [N, I](int p) { return (N / I) * (p % I) + p / I; };
     /* FAKE_ENCODE (the reference's default, CSimulate.cpp:103-104: GenMatrix is not shipped) or, with --encode, random
      * information bits through the encoder derived from the code table (reference #else branch :106-107) */
     if (encode) { ldpc->GenMsgSeq(); ldpc->Encode(); }
     else ldpc->FakeEncoder();
-    /* interleave (identity for InterleaveModType 1) + modulate once per 50 calls, reference CSimulate.cpp:111-116.
+    /* interleave + modulate once per 50 calls, reference CSimulate.cpp:111-116.
      * outputBits of a group is [32][K] then [32][M]; frame m's bit k sits at m*N + k after
      * BeforeModulationInterleaver (CModulate.cpp:95-148).  With FakeEncoder every stream sends the same 32 frames:
      * one modulated sequence serves all of them. */
@@ -87,24 +99,21 @@ void CSimulate::Run()
         if (ModulationType == 1) {
             float* dst = BPSKModSeq.data() + (size_t)g * sym;
             for (int m = 0; m < 32; ++m) for (int k = 0; k < N; ++k) dst[(size_t)m * N + k] = 2.0f * tx_bit(m, k) - 1.0f; /* CModulate.cpp:368 */
-        } else if (ModulationType == 2) {
+        } else { /* Modulation (reference CModulate.cpp:216-264): even positions index the in-phase entry MSB first, odd ones the quadrature entry */
             Complex8* dst = ModSeq.data() + (size_t)g * sym;
-            for (size_t i = 0; i < bits / 2; ++i) {
-                const size_t b0 = 2 * i, b1 = 2 * i + 1;
-                dst[i].real = table_qpsk[tx_bit((int)(b0 / N), (int)(b0 % N))];
-                dst[i].imag = table_qpsk[tx_bit((int)(b1 / N), (int)(b1 % N))];
-            }
-        } else { /* 16-QAM: I index = 2*b0 + b2, Q index = 2*b1 + b3 (reference CModulate.cpp:253-259, half_sym 2) */
-            Complex8* dst = ModSeq.data() + (size_t)g * sym;
-            for (size_t i = 0; i < bits / 4; ++i) {
-                int b[4];
-                for (int u = 0; u < 4; ++u) { const size_t pos = 4 * i + u; b[u] = tx_bit((int)(pos / N), (int)(pos % N)); }
-                dst[i].real = table_16qam[2 * b[0] + b[2]];
-                dst[i].imag = table_16qam[2 * b[1] + b[3]];
+            for (size_t i = 0; i < bits / (size_t)Q; ++i) {
+                int idx_i = 0, idx_q = 0;
+                for (int u = 0; u < Q; ++u) {
+                    const size_t pos = (size_t)Q * i + u;
+                    const int b = tx_bit((int)(pos / N), code_bit((int)(pos % N)));
+                    if (u & 1) idx_q += b << (half - u / 2 - 1); else idx_i += b << (half - u / 2 - 1);
+                }
+                dst[i].real = axis[idx_i];
+                dst[i].imag = axis[idx_q];
             }
         }
     }
-    if (device_frontend) ldpc->DeviceFrames(decode_method, encode); /* the 32 frames of every stream, once per 50 calls */
+    if (device_frontend) ldpc->DeviceFrames(decode_method, encode, InterleaveModType); /* the 32 frames of every stream, once per 50 calls */
     std::vector<float> llr(device_frontend ? 0 : (size_t)m_streams * bits);
     std::vector<int> BFiters_((size_t)m_streams * 51, 0); /* per stream, reference CSimulate.cpp:99 */
     std::vector<uint32_t> seeds(m_streams);
@@ -112,7 +121,7 @@ void CSimulate::Run()
     for (int call = 0; call < 50; ++call) {
         TestFrame += 32ul * m_streams;
         if (device_frontend) {
-            if (ModulationType == 1) { fprintf(stderr, "--device-frontend needs modType 2 or 4\n"); exit(EXIT_FAILURE); }
+            if (ModulationType == 1) { fprintf(stderr, "--device-frontend needs a QAM modType (2, 4, 6, 8)\n"); exit(EXIT_FAILURE); }
 
             ldpc->DeviceChannel(decode_method, seeds.data(), m_draws.data(), ModulationType, sigma, scale);
             const uint64_t n = ldpc->DrawsPerGroup(ModulationType);
@@ -137,16 +146,20 @@ void CSimulate::Run()
             if (ModulationType == 1) {
                 ch.BPSKAWGNChannel(BPSKModSeq.data() + (encode ? (size_t)s * sym : 0), sigma);
                 for (size_t i = 0; i < bits; ++i) dst[i] = ch.BPSKSymbol[i];
-            } else if (ModulationType == 2) {
-                ch.AWGNChannel(ModSeq.data() + (encode ? (size_t)s * sym : 0), (float)(sigma / sqrt(2))); /* reference CSimulate.cpp:126 */
-                for (size_t i = 0; i < bits / 2; ++i) { dst[2 * i] = ch.SymbolSeq[i].real; dst[2 * i + 1] = ch.SymbolSeq[i].imag; } /* Demodulation, CModulate.cpp:276-281 */
             } else {
-                ch.AWGNChannel(ModSeq.data() + (encode ? (size_t)s * sym : 0), (float)(sigma / sqrt(2)));
-                for (size_t i = 0; i < bits / 4; ++i) { /* max-log demapper, reference CModulate.cpp:283-293 */
-                    dst[4 * i] = ch.SymbolSeq[i].real;
-                    dst[4 * i + 1] = ch.SymbolSeq[i].imag;
-                    dst[4 * i + 2] = fabs(ch.SymbolSeq[i].real) - 0.6324555;
-                    dst[4 * i + 3] = fabs(ch.SymbolSeq[i].imag) - 0.6324555;
+                ch.AWGNChannel(ModSeq.data() + (encode ? (size_t)s * sym : 0), (float)(sigma / sqrt(2))); /* reference CSimulate.cpp:126 */
+                for (size_t i = 0; i < bits / (size_t)Q; ++i) { /* max-log Demodulation, every level stored as float (CModulate.cpp:273-362) */
+                    float l[8];
+                    l[0] = ch.SymbolSeq[i].real;
+                    l[1] = ch.SymbolSeq[i].imag;
+                    for (int n = 1; n < half; ++n) {
+                        l[2 * n] = fabs(l[2 * n - 2]) - fold[n - 1];
+                        l[2 * n + 1] = fabs(l[2 * n - 1]) - fold[n - 1];
+                    }
+                    for (int u = 0; u < Q; ++u) { /* de-interleave: frame-major by code bit */
+                        const size_t pos = (size_t)Q * i + u;
+                        dst[pos / N * N + (size_t)code_bit((int)(pos % N))] = l[u];
+                    }
                 }
             }
             /* AfterDeModulationDeInterleaver (CModulate.cpp:152-212) + float2LimitChar_4bit, frame-major -> [32][K] | [32][M] */

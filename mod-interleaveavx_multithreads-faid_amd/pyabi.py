@@ -69,6 +69,7 @@ SYMBOLS = {
     "lnsfaid_frontend_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_size_t, C.c_int32,
                                           C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "lnsfaid_frontend_draws_per_group": (C.c_uint64, [C.c_void_p, C.c_int32]),
+    "lnsfaid_frontend_set_interleave": (C.c_int, [C.c_void_p, C.c_int32]),
     "lnsfaid_frontend_set_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "lnsfaid_frontend_input_bits": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "lnsfaid_io_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),

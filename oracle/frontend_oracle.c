@@ -133,3 +133,55 @@ void lnsfaid_frontend_qam16_group(lnsfaid_frontend* fe, int n_var, int n_check, 
         }
     }
 }
+
+/* ---- any modulation order the reference maps (QPSK, 16-, 64-, 256-QAM) and its block interleaver ----------------
+ * BeforeModulationInterleaver (CModulate.cpp:134-146): inside every frame, position p = I * i + j carries code bit
+ * k = (B / I) * j' ... precisely InterLeaveSeq[m B + j I + i] = ILSeq[m B + (B / I) i + j], I = InterleaveModType,
+ * B = bits per frame; AfterDeModulationDeInterleaver (:152-166) is its inverse.  Modulation (:216-264): symbol s takes
+ * positions M s .. M s + M - 1; the even ones index the in-phase table entry MSB first, the odd ones the quadrature
+ * entry.  Demodulation (:273-362): max-log, l0 = real, l1 = imag, l(2n) = |l(2n-2)| - c_n, l(2n+1) = |l(2n-1)| - c_n with
+ * every level stored as float before it feeds the next. */
+static const float k_table_qpsk[2] = { -0.707107f, 0.707107f };                                   /* CModulate.cpp:4 */
+static const float k_table_16qam[4] = { -0.316228f, -0.948683f, 0.316228f, 0.948683f };           /* :5 */
+static const float k_table_64qam[8] = { -0.462910f, -0.154303f, -0.771517f, -1.08012f, 0.462910f, 0.154303f, 0.771517f, 1.08012f }; /* :6 */
+static const float k_table_256qam[16] = { -0.383482f, -0.536875f, -0.230089f, -0.076696f, -0.843661f, -0.690268f, -0.997054f, -1.150447f,
+                                          0.383482f, 0.536875f, 0.230089f, 0.076696f, 0.843661f, 0.690268f, 0.997054f, 1.150447f }; /* :7 */
+
+int lnsfaid_frontend_group(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* bits, int frame_stride, int mod_type,
+                           int interleave, float sigma, float scale, int8_t* fixInput)
+{
+    static const double c16[1] = { 0.6324555 }, c64[2] = { 0.6172134, 0.3086067 }, c256[3] = { 0.613568, 0.306784, 0.153392 };
+    const float* table = mod_type == 2 ? k_table_qpsk : mod_type == 4 ? k_table_16qam : mod_type == 6 ? k_table_64qam
+                       : mod_type == 8 ? k_table_256qam : 0;
+    const double* cl = mod_type == 4 ? c16 : mod_type == 6 ? c64 : c256;
+    const long total = 32L * n_var;
+    if (!table || interleave < 1 || n_var % interleave != 0 || total % mod_type != 0) return -1;
+    const int K = n_var - n_check, half = mod_type / 2;
+    const float sigma_ch = (float)(sigma / sqrt(2));
+    for (long s = 0; s < total / mod_type; ++s) {
+        int idx_i = 0, idx_q = 0;
+        long kk[8];
+        for (int u = 0; u < mod_type; ++u) {
+            const long pos = (long)mod_type * s + u;
+            const int m = (int)(pos / n_var), p = (int)(pos % n_var);
+            const int k = (n_var / interleave) * (p % interleave) + p / interleave; /* code bit at this position */
+            kk[u] = (long)m * n_var + k;
+            const int b = bits ? bits[(size_t)m * frame_stride + k] : 0;
+            if (u & 1) idx_q += b << (half - u / 2 - 1); else idx_i += b << (half - u / 2 - 1);
+        }
+        float l[8];
+        l[0] = random_norm(sigma_ch, fe) + table[idx_i];
+        l[1] = random_norm(sigma_ch, fe) + table[idx_q];
+        for (int n = 1; n < half; ++n) {
+            l[2 * n] = fabs(l[2 * n - 2]) - cl[n - 1];
+            l[2 * n + 1] = fabs(l[2 * n - 1]) - cl[n - 1];
+        }
+        for (int u = 0; u < mod_type; ++u) {
+            const int m = (int)(kk[u] / n_var), k = (int)(kk[u] % n_var);
+            const int8_t q = quantise_4bit(l[u], scale);
+            if (k < K) fixInput[(size_t)m * K + k] = q;
+            else fixInput[(size_t)32 * K + (size_t)m * n_check + (k - K)] = q;
+        }
+    }
+    return 0;
+}

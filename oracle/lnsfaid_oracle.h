@@ -48,6 +48,11 @@ void lnsfaid_frontend_qpsk_group(lnsfaid_frontend* fe, int n_var, int n_check, c
 /* same with 32 different frames, frames = [32][n_var] bits */
 void lnsfaid_frontend_qpsk_frames(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* frames, float sigma,
                                   float scale, int8_t* fixInput);
+/* General form: modulation order mod_type in {2, 4, 6, 8} (QPSK, 16-, 64-, 256-QAM, CModulate.cpp:4-7, :216-362), block
+ * interleaver InterleaveModType = interleave >= 1 (CModulate.cpp:95-212), bits = sent code bits with `frame_stride`
+ * between frames (0: one codeword for all 32 frames; NULL: all-zero).  Returns -1 for sizes the reference cannot map. */
+int lnsfaid_frontend_group(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* bits, int frame_stride, int mod_type,
+                           int interleave, float sigma, float scale, int8_t* fixInput);
 void lnsfaid_frontend_qam16_group(lnsfaid_frontend* fe, int n_var, int n_check, const int8_t* codeword, float sigma,
                                   float scale, int8_t* fixInput);
 

@@ -39,6 +39,7 @@ _SYMS = {
     "lnsfaid_frontend_sigma": (C.c_float, [C.c_float, C.c_int, C.c_double]),
     "lnsfaid_frontend_qpsk_group": (None, [C.POINTER(Frontend), C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     "lnsfaid_frontend_qpsk_frames": (None, [C.POINTER(Frontend), C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
+    "lnsfaid_frontend_group": (C.c_int, [C.POINTER(Frontend), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "lnsfaid_frontend_qam16_group": (None, [C.POINTER(Frontend), C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
 }
 
@@ -105,12 +106,13 @@ class ReferenceChannel:
 
     RATE = 0.8444444  # m_Rate, reference CLDPC.cpp:4780
 
-    def __init__(self, code50, seed=101, scale=13.0, mod_type=2):
+    def __init__(self, code50, seed=101, scale=13.0, mod_type=2, interleave=1):
         self.lib = load()
         self.code50 = code50
         self.fe = Frontend()
         self.scale = scale
-        self.mod_type = mod_type  # 2 QPSK, 4 16-QAM (Profile.txt modType)
+        self.mod_type = mod_type  # 2 QPSK, 4 16-QAM, 6 64-QAM, 8 256-QAM (Profile.txt modType)
+        self.interleave = interleave  # Profile.txt InterleaveModType
         self.lib.lnsfaid_frontend_seed(C.byref(self.fe), seed)
 
     def groups(self, eb_n0_db, n_groups, codeword=None, frames=None):
@@ -118,8 +120,21 @@ class ReferenceChannel:
         every group (the driver with a real encoder: encoded once per 50 calls, reference CSimulate.cpp:103-116)."""
         N, M = self.code50.N, self.code50.M
         sigma = self.lib.lnsfaid_frontend_sigma(eb_n0_db, self.mod_type, self.RATE)
-        gen = {2: self.lib.lnsfaid_frontend_qpsk_group, 4: self.lib.lnsfaid_frontend_qam16_group}[self.mod_type]
         out = np.empty((n_groups, 32 * N), dtype=np.int8)
+        if self.mod_type > 4 or self.interleave != 1:  # the general restatement (also covers 2 / 4, see test_oracle.py)
+            bits, stride = None, 0
+            if frames is not None:
+                frames = np.ascontiguousarray(frames, dtype=np.int8).reshape(32, N)
+                bits, stride = frames.ctypes.data, N
+            elif codeword is not None:
+                codeword = np.ascontiguousarray(codeword, dtype=np.int8)
+                bits = codeword.ctypes.data
+            for g in range(n_groups):
+                rc = self.lib.lnsfaid_frontend_group(C.byref(self.fe), N, M, bits, stride, self.mod_type, self.interleave, sigma,
+                                                     self.scale, out[g].ctypes.data)
+                assert rc == 0
+            return out.reshape(-1)
+        gen = {2: self.lib.lnsfaid_frontend_qpsk_group, 4: self.lib.lnsfaid_frontend_qam16_group}[self.mod_type]
         if frames is not None:
             assert self.mod_type == 2
             frames = np.ascontiguousarray(frames, dtype=np.int8).reshape(32, N)

@@ -69,3 +69,33 @@ def test_decode_of_device_generated_batch(abi, lib, code50):
     assert np.array_equal(d_out.cpu().numpy(), ref) and np.array_equal(d_st.cpu().numpy(), rst)
     assert cnt == oa.Oracle(code50, cfg).count_errors(ref, None, n)
     dec.close()
+
+
+@pytest.mark.parametrize("mod_type,interleave,scale,eb_n0", [(6, 1, 12.5, 14.0), (8, 1, 40.0, 19.0), (2, 2, 13.0, 3.8), (4, 4, 12.5, 8.6),
+                                                             (6, 3, 12.5, 14.0), (8, 8, 40.0, 19.0)],
+                         ids=["64qam", "256qam", "qpsk_il2", "16qam_il4", "64qam_il3", "256qam_il8"])
+def test_device_frontend_higher_orders_and_interleaver(abi, lib, code50, encoder, mod_type, interleave, scale, eb_n0):
+    """64- / 256-QAM (reference CModulate.cpp:6-7, :216-264, :327-356) and the block interleaver InterleaveModType > 1
+    (CModulate.cpp:95-212): device generator against the restated channel, with 32 different frames per stream
+    (lnsfaid_frontend_set_frames).  No reference output exists for these modes: the two restatements check each other."""
+    seeds = [101, 107]
+    K, N = code50.K, code50.N
+    rng = np.random.default_rng(5)
+    frames = [encoder.encode(rng.integers(0, 2, (32, K), dtype=np.uint8)) for _ in seeds]  # [32, N] each
+    dec = abi.Decoder(code50, abi.default_cfg(2, 10), 0, 2)
+    out_layout = np.concatenate([np.concatenate([f[:, :K].reshape(-1), f[:, K:].reshape(-1)]) for f in frames]).astype(np.int8)
+    info = np.concatenate([f[:, :K].reshape(-1) for f in frames]).astype(np.int8)
+    assert lib.lnsfaid_frontend_set_frames(dec.ctx, out_layout.ctypes.data, info.ctypes.data, 2) == 0
+    assert lib.lnsfaid_frontend_set_interleave(dec.ctx, interleave) == 0
+    per_group = lib.lnsfaid_frontend_draws_per_group(dec.ctx, mod_type)
+    assert per_group == 32 * N // mod_type * 4
+    want = np.concatenate([oa.ReferenceChannel(code50, s, scale, mod_type=mod_type, interleave=interleave).groups(eb_n0, 1, frames=f)
+                           for s, f in zip(seeds, frames)])
+    got = _device_groups(abi, lib, dec, code50, seeds, [0, 0], mod_type, eb_n0, scale).cpu().numpy()
+    diff = got != want
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1 and diff.sum() <= diff.size * 1e-5
+    # the mapping is consistent end to end: at this Eb/N0 the decoder returns the sent frames
+    ref, _ = oa.decode_mt(code50, abi.default_cfg(2, 10), want, 2, kind="avx2")
+    assert np.array_equal(ref.reshape(2, 32, N), np.stack(frames))
+    assert lib.lnsfaid_frontend_set_interleave(dec.ctx, 7) != 0  # must divide the frame length
+    dec.close()

@@ -179,10 +179,11 @@ def test_oms_factors_and_nondefault_tables(abi, code50):
     d.close()
 
 
-@pytest.mark.parametrize("mod_type,method,scale,eb_n0,extra", [(2, 2, 13.0, 3.5, []), (4, 5, 12.5, 8.1, []),
-                                                               (2, 2, 13.0, 3.5, ["--device-frontend"])],
-                         ids=["qpsk_faid", "16qam_2b1c", "qpsk_faid_device_frontend"])
-def test_host_driver_sweep_point_matches_oracle(abi, code50, tmp_path, mod_type, method, scale, eb_n0, extra):
+@pytest.mark.parametrize("mod_type,method,scale,eb_n0,extra,interleave",
+                         [(2, 2, 13.0, 3.5, [], 1), (4, 5, 12.5, 8.1, [], 1), (2, 2, 13.0, 3.5, ["--device-frontend"], 1),
+                          (6, 2, 12.5, 12.6, [], 3), (6, 2, 12.5, 12.6, ["--device-frontend"], 3)],
+                         ids=["qpsk_faid", "16qam_2b1c", "qpsk_faid_device_frontend", "64qam_il3", "64qam_il3_device_frontend"])
+def test_host_driver_sweep_point_matches_oracle(abi, code50, tmp_path, mod_type, method, scale, eb_n0, extra, interleave):
     """The CLDPC/CSimulate-shaped C++ driver (host/lnsfaid_sim): 4 streams (reference threads 0..3, seeds
     101, 103, 107, 109), one round of 50 calls at one Eb/N0 point; counters against the oracle fed by the restated
     channel with the same seeds.  Covers Profile.txt parsing, the DecodeMethod switch and the host front-end."""
@@ -192,7 +193,8 @@ def test_host_driver_sweep_point_matches_oracle(abi, code50, tmp_path, mod_type,
     prof = open(os.path.join(oa.PKG_DIR, "host", "Profile.txt")).read()
     prof = prof.replace("StartSNR: 3.3", "StartSNR: %g" % eb_n0).replace("EndSNR: 3.85", "EndSNR: %g" % (eb_n0 + 0.05))
     prof = prof.replace("DecodeMethod: 2", "DecodeMethod: %d" % method).replace("modType: 2", "modType: %d" % mod_type)
-    prof = prof.replace("scale: 13", "scale: %g" % scale)
+    prof = prof.replace("scale: 13", "scale: %g" % scale).replace("InterleaveModType: 1", "InterleaveModType: %d" % interleave)
+    assert "InterleaveModType: %d" % interleave in prof
     (tmp_path / "Profile.txt").write_text(prof)
     res = subprocess.run([exe, "--streams", "4", "--gpus", "1", "--max-rounds", "1"] + extra, cwd=tmp_path, capture_output=True,
                          text=True, timeout=600)
@@ -202,7 +204,7 @@ def test_host_driver_sweep_point_matches_oracle(abi, code50, tmp_path, mod_type,
     cfg = abi.default_cfg(method, 10)
     want = [0, 0, 0, 0]
     for s, seed in enumerate([101, 103, 107, 109]):
-        fix = oa.ReferenceChannel(code50, seed, scale, mod_type=mod_type).groups(eb_n0, 50)
+        fix = oa.ReferenceChannel(code50, seed, scale, mod_type=mod_type, interleave=interleave).groups(eb_n0, 50)
         dec, _ = oa.decode_mt(code50, cfg, fix, 50, kind="avx2")
         c = oa.Oracle(code50, cfg).count_errors(dec, None, 50)
         want = [w + x for w, x in zip(want, c)]

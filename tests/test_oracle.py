@@ -184,3 +184,32 @@ def test_method4_is_oms_followed_by_dtbf(abi, code50):
     assert np.array_equal(a3, b) and np.array_equal(s3, sb)
     c3, sc3 = oa.decode_mt(code50, abi.default_cfg(3, 10), fix, 4)
     assert sc3[:, 1].max() > 0 and not np.array_equal(c3, b)
+
+
+@pytest.mark.parametrize("mod_type,interleave", [(2, 1), (4, 1), (6, 1), (8, 1), (2, 4), (6, 3), (8, 8)])
+def test_general_channel_restatement(code50, encoder, mod_type, interleave):
+    """oracle/frontend_oracle.c::lnsfaid_frontend_group: equals the QPSK / 16-QAM special cases bit for bit, and for
+    every order and interleaver depth a noiseless pass returns LLRs whose decode is the sent frames (mapping, demapper and
+    (de)interleaver are mutually consistent)."""
+    rng = np.random.default_rng(3)
+    frames = encoder.encode(rng.integers(0, 2, (32, code50.K), dtype=np.uint8))
+    lib = oa.load()
+    import ctypes as C
+    if interleave == 1 and mod_type <= 4:
+        cw = frames[0]
+        a = oa.ReferenceChannel(code50, 101, 13.0, mod_type=mod_type).groups(5.0, 1, codeword=cw)
+        fe = oa.Frontend()
+        lib.lnsfaid_frontend_seed(C.byref(fe), 101)
+        sigma = lib.lnsfaid_frontend_sigma(5.0, mod_type, oa.ReferenceChannel.RATE)
+        out = np.empty(32 * code50.N, dtype=np.int8)
+        assert lib.lnsfaid_frontend_group(C.byref(fe), code50.N, code50.M, cw.ctypes.data, 0, mod_type, 1, sigma, 13.0, out.ctypes.data) == 0
+        assert np.array_equal(out, a)
+    fe = oa.Frontend()
+    lib.lnsfaid_frontend_seed(C.byref(fe), 7)
+    out = np.empty(32 * code50.N, dtype=np.int8)
+    fr = np.ascontiguousarray(frames, dtype=np.int8)
+    scale = 40.0 if mod_type == 8 else 13.0  # 256-QAM: the least significant level is 0.077, below 1 / 13
+    assert lib.lnsfaid_frontend_group(C.byref(fe), code50.N, code50.M, fr.ctypes.data, code50.N, mod_type, interleave, 0.0, scale, out.ctypes.data) == 0
+    lib_cfg = oa.pyabi.default_cfg(2, 10)
+    dec, _ = oa.Oracle(code50, lib_cfg, "avx2").decode(out, 1)
+    assert np.array_equal(dec.reshape(32, code50.N), frames)
