@@ -187,6 +187,11 @@ int lnsfaid_count_errors_device(lnsfaid_ctx* ctx, const int8_t* d_decodedBits,
  */
 int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, const uint64_t* draws_before, size_t n_streams,
                             int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput);
+/* Same with an explicit generator state per stream: states[3 s .. 3 s + 2] = RS.IX, RS.IY, RS.IZ of stream s at
+ * draws_before[s] = 0, e.g. a row of the lastSeed table the driver writes to Temp.txt (main.cpp:200-207), which the
+ * reference compiles back in under CONTINUE_SEED (CChannel.cpp:4-41, :116-119). */
+int lnsfaid_frontend_device_states(lnsfaid_ctx* ctx, const uint32_t* states, const uint64_t* draws_before, size_t n_streams,
+                                   int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput);
 uint64_t lnsfaid_frontend_draws_per_group(const lnsfaid_ctx* ctx, int32_t mod_type);
 
 /* Profile.txt InterleaveModType for lnsfaid_frontend_device: the block interleaver of BeforeModulationInterleaver /

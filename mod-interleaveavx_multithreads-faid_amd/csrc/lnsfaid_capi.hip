@@ -531,19 +531,19 @@ extern "C" uint64_t lnsfaid_frontend_draws_per_group(const lnsfaid_ctx* ctx, int
     return (uint64_t)32 * (uint64_t)ctx->n_var / (uint64_t)mod_type * 4u;
 }
 
-extern "C" int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, const uint64_t* draws_before, size_t n_streams,
-                                       int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput)
+extern "C" int lnsfaid_frontend_device_states(lnsfaid_ctx* ctx, const uint32_t* states, const uint64_t* draws_before, size_t n_streams,
+                                              int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput)
 {
-    if (!ctx || !seeds || !draws_before || !d_fixInput || (mod_type != 2 && mod_type != 4 && mod_type != 6 && mod_type != 8)) return LNSFAID_E_INVAL;
+    if (!ctx || !states || !draws_before || !d_fixInput || (mod_type != 2 && mod_type != 4 && mod_type != 6 && mod_type != 8)) return LNSFAID_E_INVAL;
     if (n_streams == 0) return LNSFAID_OK;
     if (n_streams > ctx->max_groups || (32L * ctx->n_var) % mod_type != 0) return LNSFAID_E_INVAL;
     HIP_TRY(hipSetDevice(ctx->device));
     if (!ctx->d_fe_seeds) {
-        HIP_TRY(hipMalloc(&ctx->d_fe_seeds, ctx->max_groups * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&ctx->d_fe_seeds, ctx->max_groups * 3 * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&ctx->d_fe_draws, ctx->max_groups * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc(&ctx->d_fe_codeword, (size_t)ctx->n_var));
     }
-    HIP_TRY(hipMemcpyAsync(ctx->d_fe_seeds, seeds, n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_fe_seeds, states, n_streams * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_fe_draws, draws_before, n_streams * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     if (codeword) HIP_TRY(hipMemcpyAsync(ctx->d_fe_codeword, codeword, (size_t)ctx->n_var, hipMemcpyHostToDevice, ctx->stream));
     /* AWGNChannel(ModSeq, sigma / sqrt(2)): float / double -> double, narrowed to float (CSimulate.cpp:126) */
@@ -552,8 +552,17 @@ extern "C" int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, 
                                codeword ? ctx->d_fe_codeword : nullptr,
                                (!codeword && ctx->fe_frames_streams >= n_streams) ? ctx->d_fe_frames : nullptr, ctx->n_var,
                                ctx->n_check, ctx->fe_interleave, d_fixInput, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream)); /* seeds / draws_before may be reused by the caller */
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); /* states / draws_before may be reused by the caller */
     return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, const uint64_t* draws_before, size_t n_streams,
+                                       int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput)
+{
+    if (!seeds) return LNSFAID_E_INVAL;
+    std::vector<uint32_t> st(3 * n_streams); /* CChannel::Initial without CONTINUE_SEED: IX = IY = IZ = seed (CChannel.cpp:121) */
+    for (size_t i = 0; i < n_streams; ++i) st[3 * i] = st[3 * i + 1] = st[3 * i + 2] = seeds[i];
+    return lnsfaid_frontend_device_states(ctx, st.data(), draws_before, n_streams, mod_type, sigma, scale, codeword, d_fixInput);
 }
 
 /* ---- measurement hooks / misc ---------------------------------------------------------------------- */

@@ -70,7 +70,7 @@ __device__ __forceinline__ size_t fix_pos(long pos, int n_var, int k_info, int n
     return k < k_info ? (size_t)m * k_info + k : (size_t)32 * k_info + (size_t)m * n_check + (k - k_info);
 }
 
-__global__ __launch_bounds__(256) void lnsfaid_frontend_kernel(const uint32_t* __restrict__ seeds,
+__global__ __launch_bounds__(256) void lnsfaid_frontend_kernel(const uint32_t* __restrict__ states,
                                                                const unsigned long long* __restrict__ draws_before, int mod_type,
                                                                float sigma_ch, float scale, const int8_t* __restrict__ codeword,
                                                                const int8_t* __restrict__ frames, int n_var, int n_check,
@@ -92,11 +92,12 @@ __global__ __launch_bounds__(256) void lnsfaid_frontend_kernel(const uint32_t* _
     };
     /* symbol i uses normals 2i and 2i+1, normal k uses uniforms 2k+1 and 2k+2 of the stream */
     const unsigned long long skip = draws_before[stream] + 4ull * (unsigned long long)first;
-    const uint32_t seed = seeds[stream];
+    /* generator state (IX, IY, IZ) of the stream at draws_before = 0: state after n draws = X0 * a^n mod m */
+    const uint32_t x0 = states[3 * stream], y0 = states[3 * stream + 1], z0 = states[3 * stream + 2];
     WH s;
-    s.ix = (uint32_t)(((unsigned long long)(seed % 61967u) * modpow(249u, skip, 61967u)) % 61967u);
-    s.iy = (uint32_t)(((unsigned long long)(seed % 63443u) * modpow(251u, skip, 63443u)) % 63443u);
-    s.iz = (uint32_t)(((unsigned long long)(seed % 63599u) * modpow(252u, skip, 63599u)) % 63599u);
+    s.ix = (uint32_t)(((unsigned long long)(x0 % 61967u) * modpow(249u, skip, 61967u)) % 61967u);
+    s.iy = (uint32_t)(((unsigned long long)(y0 % 63443u) * modpow(251u, skip, 63443u)) % 63443u);
+    s.iz = (uint32_t)(((unsigned long long)(z0 % 63599u) * modpow(252u, skip, 63599u)) % 63599u);
     const double sigma = (double)sigma_ch;
     const long last = first + FE_RUN < symbols ? first + FE_RUN : symbols;
     /* Modulation / Demodulation / (de)interleaver of reference CModulate.cpp:95-362 for QPSK, 16-, 64- and 256-QAM: symbol i

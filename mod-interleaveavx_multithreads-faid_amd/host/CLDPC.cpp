@@ -144,15 +144,15 @@ void CLDPC::DeviceFrames(int decode_method, bool per_stream_frames, int interlea
     if (rc) die("lnsfaid_frontend_set_frames", rc);
 }
 
-void CLDPC::DeviceChannel(int decode_method, const uint32_t* seeds, const uint64_t* draws_before, int mod_type, float sigma,
+void CLDPC::DeviceChannel(int decode_method, const uint32_t* states, const uint64_t* draws_before, int mod_type, float sigma,
                           float scale)
 {
     lnsfaid_ctx* ctx = context(decode_method);
     int8_t* d_fix = nullptr;
     int rc = lnsfaid_io_buffers(ctx, &d_fix, nullptr, nullptr);
     if (rc) die("lnsfaid_io_buffers", rc);
-    rc = lnsfaid_frontend_device(ctx, seeds, draws_before, (size_t)m_groups, mod_type, sigma, scale, nullptr, d_fix);
-    if (rc) die("lnsfaid_frontend_device", rc);
+    rc = lnsfaid_frontend_device_states(ctx, states, draws_before, (size_t)m_groups, mod_type, sigma, scale, nullptr, d_fix);
+    if (rc) die("lnsfaid_frontend_device_states", rc);
     m_device_io = true;
 }
 

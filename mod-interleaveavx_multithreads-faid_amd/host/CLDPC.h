@@ -66,7 +66,8 @@ public:
     /* with per_stream_frames the device front-end sends outputBits (after Encode) instead of the all-zero codeword and
      * CalculateErrors compares with inputBits */
     void DeviceFrames(int decode_method, bool per_stream_frames, int interleave_mod_type = 1);
-    void DeviceChannel(int decode_method, const uint32_t* seeds, const uint64_t* draws_before, int mod_type, float sigma,
+    /* states: RS.IX, RS.IY, RS.IZ per group (3 words each) at draws_before = 0 */
+    void DeviceChannel(int decode_method, const uint32_t* states, const uint64_t* draws_before, int mod_type, float sigma,
                        float scale);
     uint64_t DrawsPerGroup(int mod_type);
 

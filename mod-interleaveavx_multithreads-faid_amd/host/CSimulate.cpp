@@ -116,17 +116,21 @@ void CSimulate::Run()
     if (device_frontend) ldpc->DeviceFrames(decode_method, encode, InterleaveModType); /* the 32 frames of every stream, once per 50 calls */
     std::vector<float> llr(device_frontend ? 0 : (size_t)m_streams * bits);
     std::vector<int> BFiters_((size_t)m_streams * 51, 0); /* per stream, reference CSimulate.cpp:99 */
-    std::vector<uint32_t> seeds(m_streams);
-    for (int s = 0; s < m_streams; ++s) seeds[s] = (uint32_t)channel[s].RandomSeed;
+    std::vector<uint32_t> states(3 * (size_t)m_streams);
     for (int call = 0; call < 50; ++call) {
         TestFrame += 32ul * m_streams;
         if (device_frontend) {
             if (ModulationType == 1) { fprintf(stderr, "--device-frontend needs a QAM modType (2, 4, 6, 8)\n"); exit(EXIT_FAILURE); }
 
-            ldpc->DeviceChannel(decode_method, seeds.data(), m_draws.data(), ModulationType, sigma, scale);
+            /* every call starts from the streams' current generator states (RS), so a resumed run continues seamlessly */
+            for (int s = 0; s < m_streams; ++s) {
+                states[3 * (size_t)s] = (uint32_t)channel[s].RS.IX;
+                states[3 * (size_t)s + 1] = (uint32_t)channel[s].RS.IY;
+                states[3 * (size_t)s + 2] = (uint32_t)channel[s].RS.IZ;
+            }
+            ldpc->DeviceChannel(decode_method, states.data(), m_draws.data(), ModulationType, sigma, scale);
             const uint64_t n = ldpc->DrawsPerGroup(ModulationType);
             for (int s = 0; s < m_streams; ++s) {
-                m_draws[s] += n;
                 /* keep RS (the resume table of Temp.txt) where the host generator would be: X <- X * a^n mod m */
                 auto jump = [n](unsigned long x, unsigned long a, unsigned long m) {
                     unsigned long r = 1, b = a % m; uint64_t e = n;

@@ -37,7 +37,7 @@ private:
     std::vector<Complex8> ModSeq;   /* modulated fixed codeword of one group (QPSK) */
     std::vector<float> BPSKModSeq;
     int m_first = 0, m_streams = 0, m_Z = 256;
-    std::vector<uint64_t> m_draws; /* uniforms consumed per stream (device front-end) */
+    std::vector<uint64_t> m_draws; /* all zero: the device front-end is handed the current generator states */
 };
 
 int SimulationSeed(int index); /* the reference's seed table, CSimulate.cpp:11-17 */

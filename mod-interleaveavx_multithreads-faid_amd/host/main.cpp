@@ -15,6 +15,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <array>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -37,15 +38,17 @@ int main(int argc, char** argv)
     int streams = 64, gpus = 1, max_rounds = 0;
     bool device_frontend = false, force_collect = false, encode = false;
     const char* profile = "Profile.txt";
+    const char* resume = nullptr;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--streams") && i + 1 < argc) streams = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--profile") && i + 1 < argc) profile = argv[++i];
         else if (!strcmp(argv[i], "--max-rounds") && i + 1 < argc) max_rounds = atoi(argv[++i]); /* 0 = reference stop rule only */
         else if (!strcmp(argv[i], "--device-frontend")) device_frontend = true; /* channel + demapper + quantiser on the GPU */
+        else if (!strcmp(argv[i], "--resume") && i + 1 < argc) resume = argv[++i]; /* lastSeed table of a Temp.txt (reference CONTINUE_SEED 1) */
         else if (!strcmp(argv[i], "--encode")) encode = true; /* random information bits + the encoder derived from H (reference FAKE_ENCODE 0) */
         else if (!strcmp(argv[i], "--collect")) force_collect = true; /* collectflag = 1 from the first call (reference: once FER < 1e-5) */
-        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R] [--device-frontend] [--encode] [--collect]\n", argv[0]); return 2; }
+        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R] [--device-frontend] [--encode] [--collect] [--resume Temp.txt]\n", argv[0]); return 2; }
     }
     if (streams < 1 || gpus < 1 || gpus > streams) { fprintf(stderr, "need 1 <= gpus <= streams\n"); return 2; }
 
@@ -62,6 +65,24 @@ int main(int argc, char** argv)
         simulate[g].device_frontend = device_frontend;
         simulate[g].encode = encode;
         simulate[g].Initial(p_simulation, first, last - first, g);
+    }
+
+    if (resume) {
+        /* reference CChannel.cpp:4-41, :116-119: the generator states main wrote to Temp.txt ("{IX,IY,IZ}," one row per
+         * worker, main.cpp:200-207) replace the seed table; the counters start again, as in the reference */
+        ifstream tin(resume);
+        if (!tin.is_open()) { cerr << "Cannot open " << resume << "\n"; exit(EXIT_FAILURE); }
+        vector<array<unsigned long, 3>> rows;
+        string line;
+        while (getline(tin, line)) {
+            unsigned long a, b, c;
+            const size_t brace = line.find('{');
+            if (brace != string::npos && sscanf(line.c_str() + brace, "{%lu,%lu,%lu}", &a, &b, &c) == 3) rows.push_back({ a, b, c });
+        }
+        if ((int)rows.size() < streams) { cerr << resume << " holds " << rows.size() << " generator states, need " << streams << "\n"; exit(EXIT_FAILURE); }
+        int idx = 0;
+        for (auto& s : simulate)
+            for (auto& ch : s.channel) { ch.RS.IX = rows[idx][0]; ch.RS.IY = rows[idx][1]; ch.RS.IZ = rows[idx][2]; ++idx; }
     }
 
     ofstream fout("Result.txt", std::ios::app);

@@ -68,6 +68,8 @@ SYMBOLS = {
     "lnsfaid_count_errors_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "lnsfaid_frontend_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_size_t, C.c_int32,
                                           C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "lnsfaid_frontend_device_states": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_size_t, C.c_int32,
+                                                 C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "lnsfaid_frontend_draws_per_group": (C.c_uint64, [C.c_void_p, C.c_int32]),
     "lnsfaid_frontend_set_interleave": (C.c_int, [C.c_void_p, C.c_int32]),
     "lnsfaid_frontend_set_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -318,6 +318,38 @@ def test_host_driver_with_encoder(abi, code50, encoder, tmp_path, extra):
     assert any(np.array_equal(first, f) for f in np.concatenate(sent))
 
 
+@pytest.mark.parametrize("extra", [[], ["--device-frontend"]], ids=["host_frontend", "device_frontend"])
+def test_host_driver_resume_from_temp_txt(abi, code50, tmp_path, extra):
+    """The lastSeed table of Temp.txt (reference main.cpp:200-207) fed back with --resume (the reference compiles it in
+    under CONTINUE_SEED, CChannel.cpp:4-41): the resumed round continues the noise streams exactly where the first round
+    stopped, on the host and on the device front-end."""
+    exe = os.path.join(oa.PKG_DIR, "host", "lnsfaid_sim")
+    eb_n0 = 3.5
+    prof = open(os.path.join(oa.PKG_DIR, "host", "Profile.txt")).read()
+    prof = prof.replace("StartSNR: 3.3", "StartSNR: %g" % eb_n0).replace("EndSNR: 3.85", "EndSNR: %g" % (eb_n0 + 0.05))
+    (tmp_path / "Profile.txt").write_text(prof)
+    base = [exe, "--streams", "2", "--gpus", "1", "--max-rounds", "1"] + extra
+    res1 = subprocess.run(base, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res1.returncode == 0, res1.stderr
+    table = re.findall(r"\{(\d+),(\d+),(\d+)\}", (tmp_path / "Temp.txt").read_text())
+    assert len(table) == 2
+    os.rename(tmp_path / "Temp.txt", tmp_path / "Saved.txt")
+    res2 = subprocess.run(base + ["--resume", "Saved.txt"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res2.returncode == 0, res2.stderr
+    row = [l for l in res2.stdout.splitlines() if re.match(r"\s*%g\s" % eb_n0, l)][-1].split()
+    got = [int(row[1]), int(row[2]), int(row[3]), int(row[6])]
+    cfg = abi.default_cfg(2, 10)
+    want = [0, 0, 0, 0]
+    for s, seed in enumerate([101, 103]):
+        ch = oa.ReferenceChannel(code50, seed, 13.0)
+        ch.groups(eb_n0, 50)  # the first round's 50 calls
+        assert (ch.fe.IX, ch.fe.IY, ch.fe.IZ) == tuple(int(x) for x in table[s])  # the table is the generator state
+        fix = ch.groups(eb_n0, 50)  # the resumed round
+        dec, _ = oa.decode_mt(code50, cfg, fix, 50, kind="avx2")
+        want = [w + x for w, x in zip(want, oa.Oracle(code50, cfg).count_errors(dec, None, 50))]
+    assert got == want, (got, want, res2.stdout)
+
+
 def _derived_code(abi, lib, drop_cols, from_block_row):
     """A second quasi-cyclic code for the generic code paths: the 50G-PON table with the circulants of the
     block columns `drop_cols` removed from block rows >= from_block_row (degree 23 -> 23 - len(drop_cols))."""
