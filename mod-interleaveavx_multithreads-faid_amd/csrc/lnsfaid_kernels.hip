@@ -450,8 +450,10 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
         C1n = US((uint32_t)(a1 & 0xffff) | ((uint32_t)b1 << 16));
         C2n = US((uint32_t)(a2 & 0xffff) | ((uint32_t)b2 << 16));
     } else {
-        C1n = pk_minu(min2, (u2)(SAT_POS_MSG)); /* CDecoder_FAID.cpp:865-866, offset 0 */
-        C2n = pk_minu(min1, (u2)(SAT_POS_MSG));
+        /* CDecoder_FAID.cpp:865-866, offset 0.  Table entries are validated to lie in 0..7 (lnsfaid_set_cfg), so the
+         * values mapped after the search need no further clamp. */
+        C1n = LATE_LUT ? min2 : pk_minu(min2, (u2)(SAT_POS_MSG));
+        C2n = LATE_LUT ? min1 : pk_minu(min1, (u2)(SAT_POS_MSG));
     }
     /* sign of the new message on edge j: XOR of all signs ^ (deg odd) ^ own sign
      * (the 0xC0 / 0x40 constants of CDecoder_FAID.cpp:902-906 fed to _mm256_sign_epi8) */
@@ -531,8 +533,8 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     if (!LF_MINSUM(METHOD)) {
         /* A zero message has no sign: store "not negative" for it, so that the back-track of the next iteration (pass 1)
          * can read "Lmn < 0" straight from the sign bit.  c2 = 0 zeroes every message of the row but the argmin's. */
-        const uint32_t Z = (U(pk_nonzero(U(C2n))) ^ 0x00010001u) * 0xffffu; /* halves with c2 == 0 */
-        const uint32_t N1 = U(pk_nonzero(U(C1n))) * 0xffffu;                /* halves with c1 != 0 */
+        const uint32_t N2 = U((s2)(0) - S(U(pk_nonzero(U(C2n))))), Z = ~N2; /* halves with c2 != 0 / == 0 as 0xffff masks */
+        const uint32_t N1 = U((s2)(0) - S(U(pk_nonzero(U(C1n)))));          /* halves with c1 != 0 */
         const unsigned long long oh = (1ull << ca) | (1ull << cb);
         const uint32_t clrL = Z & ~((uint32_t)oh & N1), clrH = Z & ~((uint32_t)(oh >> 32) & N1);
         nXL = __builtin_amdgcn_bitop3_b32(nXL, Fn, clrL, 0x14); /* (a ^ b) & ~c */

@@ -29,6 +29,19 @@ DEF_KERNEL(k_xor_lit128, L8S("v_xor_b32", "0x80"))
 DEF_KERNEL(k_add_e64, L8("v_add_u32_e64", "%8"))
 DEF_KERNEL(k_lshr_inl, L8S("v_lshrrev_b32", "3"))
 DEF_KERNEL(k_pk_min_inl, L8("v_pk_min_i16", "31 op_sel_hi:[1,0]"))
+__global__ void k_lshr_b64(uint32_t* out, uint32_t seed) {
+    unsigned long long a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7;
+    uint32_t sh = (seed & 31) + 1;
+    for (int i = 0; i < REP; ++i) {
+        asm volatile("v_lshrrev_b64 %0, %4, %0\nv_lshrrev_b64 %1, %4, %1\nv_lshrrev_b64 %2, %4, %2\nv_lshrrev_b64 %3, %4, %3\n"
+                     "v_lshlrev_b64 %0, %4, %0\nv_lshlrev_b64 %1, %4, %1\nv_lshlrev_b64 %2, %4, %2\nv_lshlrev_b64 %3, %4, %3\n"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(sh));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3);
+}
+DEF_KERNEL(k_mul_lo, L8("v_mul_lo_u32", "%8"))
+DEF_KERNEL(k_bitop3, L8("v_bitop3_b32", "%8, %9 bitop3:0x96"))
+DEF_KERNEL(k_dot4, L8("v_dot4_u32_u8", "%8, %9"))
 DEF_KERNEL(k_add_u32, L8("v_add_u32", "%8"))
 DEF_KERNEL(k_xor, L8("v_xor_b32", "%8"))
 DEF_KERNEL(k_pk_add_u16, L8("v_pk_add_u16", "%8"))
@@ -101,6 +114,8 @@ int main() {
     run(k_and_lit, "v_and lit32", d, B, T, ghz, 8); run(k_and_inl, "v_and inline", d, B, T, ghz, 8); run(k_and_sgpr, "v_and sgpr", d, B, T, ghz, 8);
     run(k_xor_lit128, "v_xor lit 0x80", d, B, T, ghz, 8); run(k_add_e64, "v_add_u32_e64", d, B, T, ghz, 8); run(k_lshr_inl, "v_lshrrev inl", d, B, T, ghz, 8);
     run(k_pk_min_inl, "pk_min inline", d, B, T, ghz, 8);
+    run(k_lshr_b64, "v_lsh{l,r}rev_b64", d, B, T, ghz, 8); run(k_mul_lo, "v_mul_lo_u32", d, B, T, ghz, 8);
+    run(k_bitop3, "v_bitop3_b32", d, B, T, ghz, 8); run(k_dot4, "v_dot4_u32_u8", d, B, T, ghz, 8);
     run(k_pk_add_u16, "v_pk_add_u16", d, B, T, ghz, 8); run(k_pk_sub_i16, "v_pk_sub_i16", d, B, T, ghz, 8);
     run(k_pk_min_i16, "v_pk_min_i16", d, B, T, ghz, 8); run(k_pk_max_u16, "v_pk_max_u16", d, B, T, ghz, 8);
     run(k_pk_lshl, "v_pk_lshlrev_b16", d, B, T, ghz, 8); run(k_pk_ashr, "v_pk_ashrrev_i16", d, B, T, ghz, 8);
