@@ -343,7 +343,8 @@ extern "C" int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput,
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         ctx->kernel_ms += ms;
         ctx->kernel_launches += 1;
-        if (getenv("LNSFAID_TRACE")) fprintf(stderr, "[lnsfaid] launch %ld: %.3f ms, %u codewords left\n", launch, ms, *ctx->h_remaining);
+        static const bool trace = getenv("LNSFAID_TRACE") != nullptr; /* read once: per-launch timing on stderr */
+        if (trace) fprintf(stderr, "[lnsfaid] launch %ld: %.3f ms, %u codewords left\n", launch, ms, *ctx->h_remaining);
         cur ^= 1;
         if (*ctx->h_remaining == 0) break;
     }
