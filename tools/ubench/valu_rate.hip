@@ -89,12 +89,13 @@ __global__ void k_lds_write_b8(uint32_t* out, uint32_t seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s[threadIdx.x];
 }
 
+static size_t g_dyn_lds = 0; /* dynamic LDS per block: 40 KB with 256-thread blocks caps residency at 4 waves per SIMD, as in the decode kernel */
 template <typename K> double run(K kern, const char* name, uint32_t* d, int blocks, int threads, double ghz, int inst_per_iter) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, 1u);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), g_dyn_lds, 0, d, 1u);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, 2u);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), g_dyn_lds, 0, d, 2u);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     // waves per SIMD = blocks*threads/64 / (256 CUs * 4 SIMDs)
@@ -127,5 +128,11 @@ int main() {
     // low occupancy: 4 waves per CU (1 per SIMD)
     run(k_pk_add_u16, "pk_add 1w/SIMD", d, 1024, 64, ghz, 8); run(k_add_u32, "add 1w/SIMD", d, 1024, 64, ghz, 8);
     run(k_pk_add_u16, "pk_add 2w/SIMD", d, 2048, 64, ghz, 8);
+    g_dyn_lds = 40 * 1024; /* 4 resident waves per SIMD */
+    printf("-- 4 resident waves per SIMD (40 KB dynamic LDS per 256-thread block) --\n");
+    run(k_add_u32, "v_add_u32 4w", d, B, T, ghz, 8); run(k_xor, "v_xor_b32 4w", d, B, T, ghz, 8); run(k_and_lit, "v_and lit 4w", d, B, T, ghz, 8);
+    run(k_bitop3, "v_bitop3 4w", d, B, T, ghz, 8); run(k_pk_add_u16, "v_pk_add_u16 4w", d, B, T, ghz, 8); run(k_pk_mad, "v_pk_mad_u16 4w", d, B, T, ghz, 8);
+    run(k_perm, "v_perm_b32 4w", d, B, T, ghz, 8); run(k_add_dep, "u32 dep 4w", d, B, T, ghz, 8); run(k_pk_dep, "pk dep 4w", d, B, T, ghz, 8);
+    g_dyn_lds = 0;
     return 0;
 }
