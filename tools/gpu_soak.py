@@ -1,0 +1,42 @@
+"""Extended parity soak (not part of the test suite: minutes of CPU time): 65 536 frames per case, every DecodeMethod at two
+Eb/N0 points, GPU (through the C ABI) against the vectorised CPU port, every frame and every per-group iteration count.
+Run on the GPU box: gpurun -- 'python tools/gpu_soak.py'."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_abi as oa  # noqa: E402
+
+torch.cuda.init()
+abi = oa.pyabi
+lib = abi.load()
+code = abi.Code50GPON(lib)
+ng = 2048
+total = bad_cases = 0
+for method in (2, 5, 1, 0, 4, 3):
+    for eb_n0 in (3.1, 3.7):
+        cfg = abi.default_cfg(method, 10)
+        if method == 0:
+            cfg.factor_1, cfg.factor_2 = 24, 26
+        fix = oa.synth_llr(ng, code.N, eb_n0, seed=4242 + 31 * method + int(10 * eb_n0))
+        d = abi.Decoder(code, cfg, 0, ng, lib)
+        t0 = time.time()
+        out, st = d.decode(fix, ng)
+        t1 = time.time()
+        d.close()
+        ref, ref_st = oa.decode_mt(code, cfg, fix, ng, kind="avx2")
+        t2 = time.time()
+        bad = int((out != ref).reshape(ng * 32, code.N).any(axis=1).sum())
+        ok = bad == 0 and np.array_equal(st, ref_st)
+        total += ng * 32
+        bad_cases += 0 if ok else 1
+        print("method %d  %.1f dB: %d frames, %d differ, stats %s  (gpu incl. PCIe %.2f s, cpu port %.1f s, mean I/J %.2f/%.2f)"
+              % (method, eb_n0, ng * 32, bad, "equal" if np.array_equal(st, ref_st) else "DIFFER", t1 - t0, t2 - t1,
+                 st[:, 0].mean(), st[:, 1].mean()), flush=True)
+print("soak: %d frames in %d cases, %d cases with differences" % (total, 12, bad_cases))
+sys.exit(1 if bad_cases else 0)
