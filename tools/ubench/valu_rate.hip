@@ -90,6 +90,30 @@ __global__ void k_lds_write_b8(uint32_t* out, uint32_t seed) {
 }
 
 static size_t g_dyn_lds = 0; /* dynamic LDS per block: 40 KB with 256-thread blocks caps residency at 4 waves per SIMD, as in the decode kernel */
+template <typename T> __global__ void k_lds_write_w(uint32_t* out, uint32_t seed) {
+    __shared__ T s[20480 / sizeof(T)];
+    uint32_t ad = (threadIdx.x + seed) & (16384 / sizeof(T) - 1);
+    for (int i = 0; i < REP; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[(ad + k * (256 / sizeof(T))) & (16384 / sizeof(T) - 1)] = (T)(i + k);
+        ad = (ad + 37) & (16384 / sizeof(T) - 1);
+    }
+    __syncthreads();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s[threadIdx.x];
+}
+template <typename T> __global__ void k_lds_read_w(uint32_t* out, uint32_t seed) {
+    __shared__ T s[20480 / sizeof(T)];
+    for (int i = threadIdx.x; i < (int)(20480 / sizeof(T)); i += blockDim.x) s[i] = (T)(i * 7 + seed);
+    __syncthreads();
+    uint32_t ad = (threadIdx.x + seed) & (16384 / sizeof(T) - 1); uint32_t acc = 0;
+    for (int i = 0; i < REP; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += (uint32_t)s[(ad + k * (256 / sizeof(T))) & (16384 / sizeof(T) - 1)];
+        ad = (ad + 37) & (16384 / sizeof(T) - 1);
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 template <typename K> double run(K kern, const char* name, uint32_t* d, int blocks, int threads, double ghz, int inst_per_iter) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), g_dyn_lds, 0, d, 1u);
@@ -128,6 +152,8 @@ int main() {
     // low occupancy: 4 waves per CU (1 per SIMD)
     run(k_pk_add_u16, "pk_add 1w/SIMD", d, 1024, 64, ghz, 8); run(k_add_u32, "add 1w/SIMD", d, 1024, 64, ghz, 8);
     run(k_pk_add_u16, "pk_add 2w/SIMD", d, 2048, 64, ghz, 8);
+    run(k_lds_write_w<uint16_t>, "ds_write_b16", d, B, T, ghz, 8); run(k_lds_write_w<uint32_t>, "ds_write_b32", d, B, T, ghz, 8);
+    run(k_lds_read_w<uint16_t>, "ds_read_u16", d, B, T, ghz, 8); run(k_lds_read_w<uint32_t>, "ds_read_b32", d, B, T, ghz, 8);
     g_dyn_lds = 40 * 1024; /* 4 resident waves per SIMD */
     printf("-- 4 resident waves per SIMD (40 KB dynamic LDS per 256-thread block) --\n");
     run(k_add_u32, "v_add_u32 4w", d, B, T, ghz, 8); run(k_xor, "v_xor_b32 4w", d, B, T, ghz, 8); run(k_and_lit, "v_and lit 4w", d, B, T, ghz, 8);
