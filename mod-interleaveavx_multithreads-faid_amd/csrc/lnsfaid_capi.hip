@@ -208,6 +208,7 @@ static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
                 && (out->lut_ef_lo[it][w] != out->lut_ef_lo[it][0] || out->lut_ef_hi[it][w] != out->lut_ef_hi[it][0]))
                 out->uniform_w = 0;
         }
+    if (cfg->decode_method == 0) out->uniform_w = (out->factor_1 == out->factor_2) ? 1 : 0; /* NMS: one factor -> patch path */
     out->bf_fast = (out->W == 3 && ((int8_t)out->alpha == 0 || (int8_t)out->alpha == 1)) ? 1 : 0;
     return LNSFAID_OK;
 }

@@ -321,7 +321,11 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
                                             const uint32_t* nxt_tab, uint32_t& tab)
 {
     constexpr int NJ = DEG > 0 ? DEG : LF_MAX_DEG;
-    constexpr bool PATCH = (METHOD != 0);
+    /* DecodeMethod 0 with Factor_1 == Factor_2 (one normalisation factor, the usual NMS): a tie between the two minima gives
+     * cste_1 == cste_2 like everywhere else, so the row carries c1 on one edge only and takes the patch path; with two
+     * different factors (NMSV) every edge with |t| == min1 carries c1 and the by-value mask is kept per edge. */
+    constexpr bool NMSV = (METHOD == 0 && !UNIW);
+    constexpr bool PATCH = !NMSV;
     uint32_t llo = f->lut_lo[itx][0], lhi = f->lut_hi[itx][0];
     uint32_t elo = f->lut_ef_lo[itx][0], ehi = f->lut_ef_hi[itx][0];
     /* UNIW: one non-decreasing table for every edge of the row.  min(LUT[a]) = LUT[min a] and likewise for the second
@@ -362,14 +366,14 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             const int eA = en_ld(ad), eB = en_ld(ad ^ 128u);
             const s2 E = S(__builtin_amdgcn_perm((uint32_t)eB, (uint32_t)eA, 0x05040100u));
             u2 mag = C2o;
-            if (METHOD == 0) { /* stored per edge: was |t| == min1 */
+            if (NMSV) { /* stored per edge: was |t| == min1 */
                 const uint32_t imb = ((j < 16 ? cur.w : cur.y) >> (j < 16 ? j : j - 16 + 8)) & 0x00010001u;
                 mag = pk_mad(US(imb), C1o - C2o, C2o);
             }
             /* Lmn = neg ? -mag : mag with neg = bit j of the sign words, so En - Lmn = En + qn * (-mag), qn = 1 - 2 * neg */
             const uint32_t nb = ((j < 16 ? XL : XH) >> (j & 15)) & 0x00010001u;
             const s2 qn = pk_1_minus_2b(nb);
-            s2 t = pk_max(pk_mad_i(qn, METHOD == 0 ? (s2)(0) - S(U(mag)) : nC2o, E), (s2)(SAT_NEG_VAR)); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
+            s2 t = pk_max(pk_mad_i(qn, NMSV ? (s2)(0) - S(U(mag)) : nC2o, E), (s2)(SAT_NEG_VAR)); /* VECTOR_SUB_AND_SATURATE_VAR_8bits */
             s2 yy;
             if (LF_MINSUM(METHOD)) {
                 yy = pk_mad_i(t, S(c64), S(0x00200020u)); /* 64 t + 32: sign(yy) = (t < 0), CDecoder_OMS.cpp:372 */
@@ -463,7 +467,11 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     /* ---- the new argmin edge, exactly (its En is still the old value: pass 2 has not started) ---- */
     uint32_t pa = 0, pb = 0, nq = 0;
     s2 en_arg = (s2)(0);
-    const uint32_t ca = U(k1) & 0xffu, cb = (U(k1) >> 16) & 0xffu; /* LF_JCODE_A / _B of the argmin edges */
+    uint32_t ca = U(k1) & 0xffu, cb = (U(k1) >> 16) & 0xffu; /* LF_JCODE_A / _B of the argmin edges */
+    if (METHOD == 0) { /* minima start from 31: with every |t| above it no edge is the argmin, c1 == c2, any edge will do */
+        ca = ca == 0xffu ? (uint32_t)LF_JCODE_A(0) : ca;
+        cb = cb == 0xffu ? (uint32_t)LF_JCODE_B(0) : cb;
+    }
     if (PATCH) {
         const uint32_t sba = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ca << 2), (int)sbtab);
         const uint32_t sbb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cb << 2), (int)sbtab);
@@ -490,7 +498,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
     uint32_t one2;
     asm volatile("s_mov_b32 %0, 0x10001" : "=s"(one2));
     uint32_t KA = 0, KB = 0; /* 64 * Lmn (+ 32 where pass 1 left the rounding to pass 2) for s_j = 1 / s_j = 0 */
-    if (METHOD != 0) {
+    if (!NMSV) {
         const s2 kp = pk_mad_i(S(U(C2n)), S(c64), LF_MINSUM(METHOD) ? (s2)(0) : (s2)(32));
         const s2 kn = pk_mad_i(S(U(C2n)), (s2)(0) - S(c64), LF_MINSUM(METHOD) ? (s2)(0) : (s2)(32));
         KA = __builtin_amdgcn_bitop3_b32(Fn, U(kp), U(kn), 0xca); /* s_j = 1: negative unless F */
@@ -502,7 +510,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             const s2 yy = S(y[j]);
             const uint32_t sm = U(yy >> (s2)(15)); /* raw sign s_j per half as a mask: 0 / 0xffff */
             s2 en;
-            if (METHOD == 0) { /* by value: every edge with |t| == min1 takes cste_1 (CLDPC.cpp:371-375) */
+            if (NMSV) { /* by value: every edge with |t| == min1 takes cste_1 (CLDPC.cpp:371-375) */
                 const s2 t = yy >> (s2)(6);
                 const u2 ne = pk_nonzero(U(pk_max(t, (s2)(0) - t)) ^ U(min1));
                 const uint32_t im = U(ne) ^ 0x00010001u;
@@ -526,7 +534,7 @@ __device__ __forceinline__ uint4 layer_step(CCode c, CCfg f, int8_t* sEn, int ti
             en_st(ad ^ 128u, en.y);
         }
     }
-    if (METHOD == 0) return make_uint4(nXL ^ Fn, ((nXH ^ Fn) & 0x00ff00ffu) | (nIH << 8), (U(C1n) << 5) | (U(C2n) << 8), nIL);
+    if (NMSV) return make_uint4(nXL ^ Fn, ((nXH ^ Fn) & 0x00ff00ffu) | (nIH << 8), (U(C1n) << 5) | (U(C2n) << 8), nIL);
     en_st(pa, en_arg.x);
     en_st(pb, en_arg.y);
     /* the new Lmn on edge j is negative iff s_j ^ F */
@@ -994,7 +1002,7 @@ extern "C" hipError_t lf_launch_decode(int method, int uniform_w, const LfKernel
                                        hipStream_t stream)
 {
     switch (method) {
-    case 0: return launch_method<0>(true, args, lds_bytes, stream); /* normalised min-sum */
+    case 0: return launch_method<0>(uniform_w != 0, args, lds_bytes, stream); /* normalised min-sum; uniform_w: Factor_1 == Factor_2 */
     case 1: return launch_method<1>(true, args, lds_bytes, stream); /* OMS has no look-up table */
     case 2: return launch_method<2>(uniform_w != 0, args, lds_bytes, stream);
     case 3: return launch_method<3>(true, args, lds_bytes, stream); /* OMS arithmetic + plain bit flipping */

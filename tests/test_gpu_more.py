@@ -456,15 +456,17 @@ def test_random_codewords(abi, code50, encoder, method, eb_n0):
 
 
 @pytest.mark.parametrize("eb_n0", [3.2, 3.6, 4.0])
-@pytest.mark.parametrize("method", [2, 5, 1, 0, 4, 3])
+@pytest.mark.parametrize("method", [2, 5, 1, 0, -1, 4, 3])
 def test_soak_against_cpu_port(abi, code50, method, eb_n0):
     """32 768 frames per case (1024 groups, several dispatch rounds of workgroups) against the vectorised CPU port, every
     frame and every per-group iteration count: the place where rare message patterns (ties, zero messages on the argmin
     edge, saturated rows) turn up."""
     ng = 1024
+    uni = method == -1  # DecodeMethod 0 with one normalisation factor: the kernel's patch path
+    method = 0 if uni else method
     cfg = abi.default_cfg(method, 10)
     if method == 0:
-        cfg.factor_1, cfg.factor_2 = 24, 26  # the shipped Profile.txt factors are OMS offsets; 0.75 / 0.81 normalisation
+        cfg.factor_1, cfg.factor_2 = (24, 24) if uni else (24, 26)  # the shipped Profile.txt factors are OMS offsets
     fix = oa.synth_llr(ng, code50.N, eb_n0, seed=1000 + 17 * method + int(eb_n0 * 10))
     d = abi.Decoder(code50, cfg, 0, ng)
     out, st = d.decode(fix, ng)

@@ -33,10 +33,12 @@ def test_decode_matches_oracle(abi, code50, method, eb_n0):
     _parity(abi, code50, method, 10, eb_n0, 4)
 
 
-@pytest.mark.parametrize("f1,f2,eb_n0,max_iter", [(24, 24, 3.6, 10), (24, 28, 3.0, 6), (1, 6, 3.6, 3), (20, 30, 4.2, 10), (3, 40, 3.6, 5),
+@pytest.mark.parametrize("f1,f2,eb_n0,max_iter", [(24, 24, 3.6, 10), (24, 24, 3.0, 10), (16, 16, 3.4, 7), (32, 32, 3.8, 10), (1, 1, 3.6, 3), (45, 45, 3.6, 6),
+                                                  (24, 28, 3.0, 6), (1, 6, 3.6, 3), (20, 30, 4.2, 10), (3, 40, 3.6, 5),
                                                   (200, 2000, 3.6, 4), (24, 24, 3.6, 1), (24, 24, 3.6, 0)])
 def test_nms_matches_oracle(abi, code50, f1, f2, eb_n0, max_iter):
-    """DecodeMethod 0 (CLDPC::Decode, reference CLDPC.cpp:214): by-value first-minimum masks, numerators over 32."""
+    """DecodeMethod 0 (CLDPC::Decode, reference CLDPC.cpp:214): numerators over 32; equal factors take the kernel's patch
+    path (one c1 edge per row), different factors the by-value first-minimum masks."""
     cfg = abi.default_cfg(0, max_iter)
     cfg.factor_1, cfg.factor_2 = f1, f2
     fix = oa.ReferenceChannel(code50, 149, 13.0).groups(eb_n0, 3)
