@@ -40,6 +40,7 @@ cal4 = (n_cw * K) / (cnt_fetch_kib * 1024.0)  # true bytes / reported bytes for 
 corrected_read = dec_fetch_kib * 1024.0 * 2.0
 out = {
     "tag": tag,
+    "kernel_source_hash": open(os.path.join(src, "kernel_source_hash.txt")).read().strip(),
     "kernel": "lnsfaid_decode_kernel<2, true>",
     "codewords_per_launch": n_cw,
     "FETCH_SIZE_KiB_raw": dec_fetch_kib,
