@@ -1,0 +1,421 @@
+/*
+ * lnsfaid_swar.h — one layer of the layered decoder with FOUR check rows per lane, byte-parallel in 32-bit registers.
+ *
+ * Mapping.  One wavefront owns one codeword; lane i owns check rows i, i+64, i+128, i+192 of every
+ * layer (block row) of the quasi-cyclic H.  Byte k of every working register belongs to row i + 64 k.  Inside a block
+ * column the a-posteriori LLRs are stored so that the four variable nodes these rows meet on one circulant share ONE
+ * LDS dword: variable node v (0..255) of the column lives in dword v mod 64, byte v div 64.  Through a circulant with
+ * shift s lane i reads dword (i + s) mod 64 and rotates it right by ((i + s) div 64) mod 4 bytes: one ds_read_b32 and
+ * one v_alignbyte_b32 instead of four byte reads and three packs, and all 64 lanes hit 64 consecutive dwords.
+ *
+ * Arithmetic is carry-free SWAR on biased bytes (every intermediate stays inside its byte, so plain 32-bit adds never
+ * carry across rows) built from the instructions gfx950 issues at the full rate (two-source 32-bit ALU operations and
+ * v_bitop3_b32) plus v_perm_b32 used three ways: as an 8-entry byte table (FAID look-up table, thermometer code, +-c
+ * constants), as a "bit 7 of every byte -> byte mask" expander (its sign-replicating selectors 8..11), and as a packer.
+ *   LDS byte        Eb = En + 120                      (En in [-31, 31])
+ *   V2C             tb = t + 128,  t = En - Lold       (one add of a per-row, per-sign constant picked by v_perm)
+ *   sign            bit 7 of ts = tb - b, b = "old message negative": the reference's back-tracked sign of a zero V2C
+ *                   (CDecoder_FAID.cpp:682: t == 0 means En == Lold, so sign(En) is the stored sign bit)
+ *   minima          thermometer code U(a), a = min(|t|, 7): bit i set iff a > i, so min = AND and
+ *                   second-min' = second-min & (min | U): two boolean operations per edge for four rows; the binary
+ *                   index of an edge attaining the minimum comes from five more AND accumulators (edges whose index
+ *                   has bit b clear) compared with the minimum afterwards — no per-edge compare / select.
+ * Reference statements restated here: CDecoder_FAID.cpp:662-929 (FAID / 2B1C rows), CDecoder_OMS.cpp:363-471 (OMS rows),
+ * CLDPC.cpp:296-375 (NMS rows).  As in the 2-rows-per-lane kernel the check-to-variable messages are kept compressed
+ * (sign bit per edge, the two magnitudes of the row, the edge that carries the larger one) and only ONE edge per row
+ * carries c1: every edge is processed as if it carried c2 and the arg-min edge is patched through LDS before pass 1 and
+ * recomputed exactly after pass 2 (DESIGN.md 3.2 explains why this is bit-exact).
+ *
+ * The file compiles for the device (hipcc) and for the host (g++, -DSW_HOST): tests/ run the very same statements on the
+ * CPU against the oracle, lane by lane (lanes of a layer are independent: they touch disjoint variable nodes).
+ */
+#ifndef LNSFAID_SWAR_H
+#define LNSFAID_SWAR_H
+
+#include <stdint.h>
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SW_DEV 1
+#define SW_FN __device__ __forceinline__
+#else
+#define SW_DEV 0
+#define SW_FN static inline
+#endif
+
+#define SW_MAX_DEG 24
+
+/* ---- the three non-trivial instructions, with host restatements of their ISA semantics -------------------------- */
+/* v_perm_b32: byte i of the result = BYTE_PERMUTE({s0, s1}, sel byte i): 0..3 bytes of s1, 4..7 bytes of s0,
+ * 8 / 9 / 10 / 11 bit 7 of byte 1 / 3 / 5 / 7 replicated, 12 -> 0x00, >= 13 -> 0xff */
+SW_FN uint32_t sw_perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+#if SW_DEV
+    return __builtin_amdgcn_perm(s0, s1, sel);
+#else
+    const uint64_t in = ((uint64_t)s0 << 32) | s1;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t s = (sel >> (8 * i)) & 0xffu;
+        uint32_t b;
+        if (s >= 13) b = 0xff;
+        else if (s == 12) b = 0;
+        else if (s >= 8) b = ((in >> (8 * (2 * (s - 8) + 1) + 7)) & 1u) ? 0xffu : 0u;
+        else b = (uint32_t)(in >> (8 * s)) & 0xffu;
+        r |= b << (8 * i);
+    }
+    return r;
+#endif
+}
+/* v_alignbyte_b32: ({s0, s1} >> (8 * s2)) & 0xffffffff; used with s2 in 0..4 only */
+SW_FN uint32_t sw_alignbyte(uint32_t s0, uint32_t s1, uint32_t s2)
+{
+#if SW_DEV
+    return __builtin_amdgcn_alignbyte(s0, s1, s2);
+#else
+    const uint64_t in = ((uint64_t)s0 << 32) | s1;
+    return (uint32_t)(in >> (8 * (s2 & 7u)));
+#endif
+}
+/* v_bitop3_b32: bit i of the result = bit ((a_i << 2) | (b_i << 1) | c_i) of the truth table */
+template <int TT>
+SW_FN uint32_t sw_bitop3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if SW_DEV
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+#else
+    uint32_t r = 0;
+    for (int m = 0; m < 8; ++m)
+        if ((TT >> m) & 1) r |= ((m & 4) ? a : ~a) & ((m & 2) ? b : ~b) & ((m & 1) ? c : ~c);
+    return r;
+#endif
+}
+#define SW_TT_SEL 0xca   /* a ? b : c            */
+#define SW_TT_XOR3 0x96  /* a ^ b ^ c            */
+#define SW_TT_AND3 0x80  /* a & b & c            */
+#define SW_TT_ANDOR 0xea /* (a & b) | c          */
+#define SW_TT_NANDOR 0xae /* (~a & b) | c        */
+#define SW_TT_A_AND_BORC 0xe0 /* a & (b | c)     */
+#define SW_TT_XORAND 0x28 /* (a ^ b) & c         */
+#define SW_TT_BFI_C 0xd8 /* c ? b : a            */
+#define SW_TT_ANDNOT_OR 0xf8 /* a | (b & c)      */
+
+/* a constant that must live in a VGPR (VOP3 takes no literal, and an SGPR operand halves the issue rate) */
+SW_FN uint32_t sw_vconst(uint32_t k)
+{
+#if SW_DEV
+    uint32_t r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(k));
+    return r;
+#else
+    return k;
+#endif
+}
+
+/* 0xff in every byte whose bit 7 is set, else 0x00 (two instructions: shift + v_perm with selectors 8..11) */
+SW_FN uint32_t sw_mask7(uint32_t x, uint32_t sel_sign) { return sw_perm(x, x << 8, sel_sign); }
+#define SW_SEL_SIGN 0x0b090a08u
+
+/* per-byte population count of the low seven bits (thermometer code -> number) */
+SW_FN uint32_t sw_popcount7(uint32_t x)
+{
+    x &= 0x7f7f7f7fu;
+    x = x - ((x >> 1) & 0x55555555u);
+    x = (x & 0x33333333u) + ((x >> 2) & 0x33333333u);
+    return (x + (x >> 4)) & 0x0f0f0f0fu;
+}
+/* 0xff in every byte that is zero; bytes must be <= 0x7f */
+SW_FN uint32_t sw_zero_mask(uint32_t x, uint32_t sel_sign) { return ~sw_mask7(x + 0x7f7f7f7fu, sel_sign); }
+
+/* ---- compressed messages of the four rows of one lane in one layer (24 bytes, streamed through HBM) ---------------
+ * x[g] bit 8 k + e : the message on edge 8 g + e of row k is negative (0 for a zero message, FAID / 2B1C)
+ * cw byte k        : c2 | c1 << 3 | (message on the arg-min edge negative) << 6
+ * pa[h]            : LDS byte addresses of the arg-min variable nodes of rows 2 h (low half) and 2 h + 1 (high half) */
+struct SwRow {
+    uint32_t x[3];
+    uint32_t cw;
+    uint32_t pa[2];
+};
+
+/* decoder constants a layer needs (uniform over the wave) */
+struct SwParams {
+    uint32_t lut_lo, lut_hi;       /* V2C_map_it* as 8 bytes (entries 0..3 / 4..7) for this iteration           */
+    uint32_t ef_lo, ef_hi;         /* error-floor table (DecodeMethod 5)                                        */
+    int32_t f1, f2;                /* Factor_1 / Factor_2 (OMS offsets, NMS numerators)                          */
+    int32_t window;                /* nombre_iterations <= floor_iter_thresh                                     */
+};
+
+/* LDS seen by the layer step: byte offsets inside the codeword's En image (block column cb at cb * 256). */
+#if SW_DEV
+struct SwLds {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    SW_FN uint32_t rd32(uint32_t a) const { return *(const lds_u32*)(size_t)a; }
+    SW_FN void wr32(uint32_t a, uint32_t v) const { *(lds_u32*)(size_t)a = v; }
+    SW_FN uint32_t rd8(uint32_t a) const { return *(const lds_u8*)(size_t)a; }
+    SW_FN void wr8(uint32_t a, uint32_t v) const { *(lds_u8*)(size_t)a = (uint8_t)v; }
+};
+#else
+struct SwLds {
+    uint8_t* base;
+    uint32_t rd32(uint32_t a) const { return (uint32_t)base[a] | ((uint32_t)base[a + 1] << 8) | ((uint32_t)base[a + 2] << 16) | ((uint32_t)base[a + 3] << 24); }
+    void wr32(uint32_t a, uint32_t v) const { base[a] = (uint8_t)v; base[a + 1] = (uint8_t)(v >> 8); base[a + 2] = (uint8_t)(v >> 16); base[a + 3] = (uint8_t)(v >> 24); }
+    uint32_t rd8(uint32_t a) const { return base[a]; }
+    void wr8(uint32_t a, uint32_t v) const { base[a] = (uint8_t)v; }
+};
+#endif
+
+#define SW_BIAS_EN 120 /* LDS byte = En + 120 */
+
+/* LDS byte position of variable node v (index inside the code word) in the interleaved image */
+SW_FN uint32_t sw_en_pos(uint32_t v) { return (v & ~255u) | ((v & 63u) << 2) | ((v >> 6) & 3u); }
+
+/* DecodeMethods whose rows follow Decode_OMS (1, 3, 4) / use the plain sign and no upper clamp on t (those and NMS, 0) */
+#define SW_OMS(M) ((M) == 1 || (M) == 3 || (M) == 4)
+#define SW_MINSUM(M) ((M) == 0 || SW_OMS(M))
+
+/* selective offset of OMS_MODE 1 on one minimum (CDecoder_OMS.cpp:388-425) */
+SW_FN int sw_oms_offset(int x, bool window, bool F, int f1, int f2)
+{
+    if (window && F) {
+        if (x < f2) x += 1;
+        if (x <= f1) x += 1;
+    } else {
+        if (x > f1) x -= 1;
+        if (x >= f2) x -= 1;
+    }
+    return x;
+}
+
+/* the two-stage saturating update En' = sat31(tc + L), tc = sat31(t) (FAID, CDecoder_FAID.cpp:672, :919-920) or
+ * max(t, -31) (min-sum decoders, CDecoder_OMS.cpp:371, :466), written as ONE clamp of t with sign-dependent limits:
+ *   L = +c : En' = c + clamp(t, -31, 31 - c)            L = -c : En' = -c + clamp(t, -31 + c, 31)   (31 + c: min-sum)
+ * Per row the five byte constants below exist in a "new message not negative" (p) and a "negative" (n) version. */
+struct SwUpd {
+    uint32_t oc[2], qc[2], lc[2], hl[2], ll[2]; /* [1]: chosen where the mask is 0xff, [0]: where it is 0x00 */
+};
+/* c: magnitude bytes (0..7); flip: byte mask, 0xff where mask polarity is inverted (row parity F) */
+template <bool MINSUM>
+SW_FN SwUpd sw_update_consts(uint32_t c, uint32_t flip)
+{
+    const uint32_t oc_p = 0x20202020u - c, oc_n = MINSUM ? 0x20202020u + c : 0x20202020u; /* over  <=> t > hi' : tb - (hi' + 1) >= 128 */
+    const uint32_t qc_p = 0x1f1f1f1fu, qc_n = 0x1f1f1f1fu - c;                            /* under <=> t < lo' : tb - lo' < 128        */
+    const uint32_t lc_p = 0x08080808u - c, lc_n = 0x08080808u + c;                        /* Eb' = tb - (8 - L)                        */
+    const uint32_t hl_p = 0x97979797u, hl_n = MINSUM ? 0x97979797u : 0x97979797u - c;     /* hi' + L + 120                             */
+    const uint32_t ll_p = 0x59595959u + c, ll_n = 0x59595959u;                            /* lo' + L + 120                             */
+    SwUpd u;
+    u.oc[1] = sw_bitop3<SW_TT_SEL>(flip, oc_n, oc_p); u.oc[0] = sw_bitop3<SW_TT_SEL>(flip, oc_p, oc_n);
+    u.qc[1] = sw_bitop3<SW_TT_SEL>(flip, qc_n, qc_p); u.qc[0] = sw_bitop3<SW_TT_SEL>(flip, qc_p, qc_n);
+    u.lc[1] = sw_bitop3<SW_TT_SEL>(flip, lc_n, lc_p); u.lc[0] = sw_bitop3<SW_TT_SEL>(flip, lc_p, lc_n);
+    u.hl[1] = sw_bitop3<SW_TT_SEL>(flip, hl_n, hl_p); u.hl[0] = sw_bitop3<SW_TT_SEL>(flip, hl_p, hl_n);
+    u.ll[1] = sw_bitop3<SW_TT_SEL>(flip, ll_n, ll_p); u.ll[0] = sw_bitop3<SW_TT_SEL>(flip, ll_p, ll_n);
+    return u;
+}
+/* tb: t + 128 per byte; ms: 0xff where bit 7 of the (back-tracked) sign word is set, i.e. the V2C is not negative */
+SW_FN uint32_t sw_update(uint32_t tb, uint32_t ms, const SwUpd& u, uint32_t sel_sign)
+{
+    const uint32_t oc = sw_bitop3<SW_TT_SEL>(ms, u.oc[1], u.oc[0]);
+    const uint32_t qc = sw_bitop3<SW_TT_SEL>(ms, u.qc[1], u.qc[0]);
+    const uint32_t lc = sw_bitop3<SW_TT_SEL>(ms, u.lc[1], u.lc[0]);
+    const uint32_t hl = sw_bitop3<SW_TT_SEL>(ms, u.hl[1], u.hl[0]);
+    const uint32_t ll = sw_bitop3<SW_TT_SEL>(ms, u.ll[1], u.ll[0]);
+    const uint32_t mo = sw_mask7(tb - oc, sel_sign); /* over  */
+    const uint32_t mq = sw_mask7(tb + qc, sel_sign); /* not under */
+    return sw_bitop3<SW_TT_SEL>(mo, hl, sw_bitop3<SW_TT_SEL>(mq, tb - lc, ll));
+}
+
+/* ---- one layer -----------------------------------------------------------------------------------------------------
+ * Tab: tab.sb(j) = block column * 256 + shift of edge j (uniform), tab.sb_dyn(idx) the same for a per-lane edge index.
+ * rowpar: byte mask, 0xff in byte k if the syndrome bit of row i + 64 k is set (only read by the OMS selective offset
+ * and the 2B1C error-floor tables); lme: unsat < floor_err_count for this codeword.
+ * METHOD 0 requires Factor_1 == Factor_2 here (one normalisation factor; the two-factor variant keeps the 2-row kernel). */
+template <int METHOD, int DEG, class Tab>
+SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, uint32_t lane, int deg, SwRow cur, bool fresh,
+                          uint32_t rowpar, bool lme)
+{
+    constexpr int NJ = DEG > 0 ? DEG : SW_MAX_DEG;
+    constexpr bool MINSUM = SW_MINSUM(METHOD);
+    const uint32_t c01 = sw_vconst(0x01010101u), c80 = sw_vconst(0x80808080u), c7f = sw_vconst(0x7f7f7f7fu);
+    const uint32_t c78 = sw_vconst(0x78787878u), c0642 = sw_vconst(0x06040200u), cfc = sw_vconst(0xfcu);
+    const uint32_t sel_sign = sw_vconst(SW_SEL_SIGN);
+    const uint32_t tid4 = lane << 2;
+
+    /* ---- the row's old messages: +-c2 on every edge (8 +- c2 as a v_perm table indexed 2 k + negative) ---- */
+    const uint32_t c2o = cur.cw & 0x07070707u, c1o = (cur.cw >> 3) & 0x07070707u;
+    const uint32_t kp = 0x08080808u - c2o, kn = 0x08080808u + c2o;
+    const uint32_t kt_lo = sw_perm(kn, kp, 0x05010400u), kt_hi = sw_perm(kn, kp, 0x07030602u);
+    /* thermometer code of min(|t|, 7); entry 7 equals what v_perm returns for a saturated selector */
+    const uint32_t tt_lo = sw_vconst(0x07030100u), tt_hi = sw_vconst(0xff3f1f0fu);
+
+    /* ---- the old arg-min edge carries c1, not c2: move its En by the difference so that "every edge carries c2" holds ---- */
+    if (!fresh) {
+        const uint32_t a0 = cur.pa[0] & 0xffffu, a1 = cur.pa[0] >> 16, a2 = cur.pa[1] & 0xffffu, a3 = cur.pa[1] >> 16;
+        const uint32_t g = lds.rd8(a0) | (lds.rd8(a1) << 8) | (lds.rd8(a2) << 16) | (lds.rd8(a3) << 24);
+        const uint32_t mneg = sw_mask7(cur.cw << 1, sel_sign); /* bit 6: the arg-min message is negative */
+        /* En - L(c1) = (En - sigma (c1 - c2)) - sigma c2 */
+        const uint32_t r = g + sw_bitop3<SW_TT_SEL>(mneg, c1o, c2o) - sw_bitop3<SW_TT_SEL>(mneg, c2o, c1o);
+        lds.wr8(a0, r); lds.wr8(a1, r >> 8); lds.wr8(a2, r >> 16); lds.wr8(a3, r >> 24);
+    }
+
+    uint32_t tb[NJ], ts[NJ], ad[NJ], rq[NJ];
+    uint32_t t1 = 0xffffffffu, t2 = 0xffffffffu, ta[5] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
+    uint32_t sx = 0;
+
+    /* ---- pass 1 (CDecoder_FAID.cpp:662-861, CDecoder_OMS.cpp:363-380) ---- */
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (DEG > 0 || j < deg) {
+            const uint32_t sb = tab.sb(j);
+            const uint32_t x4 = tid4 + ((sb & 255u) << 2);
+#if SW_DEV
+            uint32_t a;
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(x4), "v"(cfc), "s"(sb & ~255u));
+#else
+            const uint32_t a = (x4 & cfc) | (sb & ~255u);
+#endif
+            const uint32_t q = x4 >> 8;
+            ad[j] = a; rq[j] = q;
+            const uint32_t d = lds.rd32(a);
+            const uint32_t r = sw_alignbyte(d, d, q);                 /* byte k = En + 120 of row k */
+            const uint32_t x0 = (j & 7) ? cur.x[j >> 3] >> (j & 7) : cur.x[j >> 3];
+            const uint32_t sel = sw_bitop3<SW_TT_ANDOR>(x0, c01, c0642);
+            const uint32_t t = r + sw_perm(kt_hi, kt_lo, sel);       /* t + 128, VECTOR_SUB_AND_SATURATE comes in pass 2 */
+            tb[j] = t;
+            /* FAID: a zero V2C takes the sign of En (CDecoder_FAID.cpp:682); En == Lold there, so it is the stored sign */
+            const uint32_t s = MINSUM ? t : t - (x0 & c01);
+            ts[j] = s;
+            sx ^= s;
+            /* |t| -> min(|t|, 7) -> thermometer: one's complement of the negative side plus 1, saturation through bit 7 */
+            const uint32_t mp = sw_mask7(t, sel_sign);                /* t >= 0 */
+            const uint32_t m = sw_bitop3<SW_TT_XOR3>(t, c7f, mp);
+            const uint32_t w = m + sw_bitop3<SW_TT_NANDOR>(mp, c01, c78);
+            const uint32_t u = sw_perm(tt_hi, tt_lo, w & 0x87878787u);
+            t2 = sw_bitop3<SW_TT_A_AND_BORC>(t2, t1, u);              /* VECTOR_MIN_2 with the old min1 */
+            t1 &= u;
+#pragma unroll
+            for (int b = 0; b < 5; ++b)
+                if (!((j >> b) & 1)) ta[b] &= u;
+        }
+    }
+
+    /* ---- the row's new magnitudes ---- */
+    uint32_t min1 = sw_popcount7(t1), min2 = sw_popcount7(t2);
+    uint32_t c1n, c2n;
+    if (METHOD == 0) {
+        /* cste = min(((min * Factor) & 0xffff) >> 5, 7) (CLDPC.cpp:337-352); minima above 7 were clamped by the
+         * thermometer, which is harmless only while 7 * Factor >> 5 already saturates...  NMS keeps |t| up to 31:
+         * this path is used by the caller only when that holds (Factor >= 37), otherwise the 2-row kernel runs. */
+        const uint32_t g = (uint32_t)(uint16_t)(int16_t)p.f1;
+        c2n = 0; c1n = 0;
+        for (int k = 0; k < 4; ++k) {
+            uint32_t a = ((((min1 >> (8 * k)) & 0xffu) * g) & 0xffffu) >> 5, b = ((((min2 >> (8 * k)) & 0xffu) * g) & 0xffffu) >> 5;
+            c2n |= (a > 7 ? 7u : a) << (8 * k);
+            c1n |= (b > 7 ? 7u : b) << (8 * k);
+        }
+    } else if (SW_OMS(METHOD)) {
+        c2n = 0; c1n = 0;
+        for (int k = 0; k < 4; ++k) {
+            const bool F = ((rowpar >> (8 * k)) & 1u) && lme;
+            int a = sw_oms_offset((int)((min1 >> (8 * k)) & 0xffu), p.window != 0, F, p.f1, p.f2);
+            int b = sw_oms_offset((int)((min2 >> (8 * k)) & 0xffu), p.window != 0, F, p.f1, p.f2);
+            c2n |= (uint32_t)((a > 7 ? 7 : a) & 0xff) << (8 * k); /* cste_2, CDecoder_OMS.cpp:432 */
+            c1n |= (uint32_t)((b > 7 ? 7 : b) & 0xff) << (8 * k); /* cste_1 */
+        }
+    } else {
+        /* uniform non-decreasing table applied after the search; offset 0 (CDecoder_FAID.cpp:864-866) */
+        c2n = sw_perm(p.lut_hi, p.lut_lo, min1);
+        c1n = sw_perm(p.lut_hi, p.lut_lo, min2);
+        if (METHOD == 5 && p.window && lme) { /* mask_eef per row (CDecoder_FAID.cpp:713-720) */
+            c2n = sw_bitop3<SW_TT_SEL>(rowpar, sw_perm(p.ef_hi, p.ef_lo, min1), c2n);
+            c1n = sw_bitop3<SW_TT_SEL>(rowpar, sw_perm(p.ef_hi, p.ef_lo, min2), c1n);
+        }
+    }
+    /* new message on edge j is negative iff s_j ^ XOR_all(s) ^ (deg odd) (the 0xC0 / 0x40 constants of
+     * CDecoder_FAID.cpp:902-917); with nn_j = bit 7 of ts_j = "V2C not negative" that is: not negative iff nn_j ^ F,
+     * F = bit 7 of the XOR of all ts */
+    const uint32_t fm = sw_mask7(sx, sel_sign);
+
+    /* ---- binary index of an edge that attains the minimum: bit b is 1 iff no edge with bit b clear attains it ---- */
+    uint32_t idx = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        const uint32_t dd = sw_bitop3<SW_TT_XORAND>(ta[b], t1, c7f);
+        idx |= ((dd + c7f) & c80) >> (7 - b);
+    }
+    /* a tie leaves the AND of the tied indices: still an edge of the row, and in a tie c1 == c2 */
+
+    /* ---- the new arg-min edge: address, exact V2C, exact new En (its En in LDS is still the old value) ---- */
+    uint32_t pa[4], gb = 0, xb = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t ik = (idx >> (8 * k)) & 31u;
+        const uint32_t sb = tab.sb_dyn(ik);
+        const uint32_t x4 = tid4 + ((sb & 255u) << 2);
+        pa[k] = ((x4 & 0xfcu) | (sb & ~255u)) + (((x4 >> 8) + (uint32_t)k) & 3u);
+        gb |= lds.rd8(pa[k]) << (8 * k);
+        xb |= ((cur.x[ik >> 3] >> ((ik & 7u) + 8u * (uint32_t)k)) & 1u) << (8 * k); /* old message on that edge negative */
+    }
+    const uint32_t selA = xb | c0642;
+    const uint32_t tbA = gb + sw_perm(kt_hi, kt_lo, selA);
+    const uint32_t tsA = MINSUM ? tbA : tbA - xb;
+    const uint32_t msA = sw_mask7(tsA, sel_sign);
+    const SwUpd u1 = sw_update_consts<MINSUM>(c1n, fm);
+    const uint32_t enA = sw_update(tbA, msA, u1, sel_sign);
+    const uint32_t negA = ~(msA ^ fm); /* byte mask: the new message on the arg-min edge is negative */
+
+    /* ---- pass 2 (CDecoder_FAID.cpp:909-929, CDecoder_OMS.cpp:452-471): every edge as if it carried c2 ---- */
+    const SwUpd u2 = sw_update_consts<MINSUM>(c2n, fm);
+    uint32_t ns[3] = { 0u, 0u, 0u };
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (DEG > 0 || j < deg) {
+            const uint32_t ms = sw_mask7(ts[j], sel_sign);
+            const uint32_t en = sw_update(tb[j], ms, u2, sel_sign);
+            const uint32_t nq = 4u - rq[j];
+            lds.wr32(ad[j], sw_alignbyte(en, en, nq));
+            /* sign bits gathered by shifting: after the 8 edges of a word the flag of edge e sits at bit e of its byte */
+            ns[j >> 3] = sw_bitop3<SW_TT_BFI_C>(ns[j >> 3] >> 1, ts[j], c80);
+        }
+    }
+    {   /* the last word holds fewer than 8 edges */
+        const int n = DEG > 0 ? DEG : deg;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int cnt = n - 8 * g < 0 ? 0 : (n - 8 * g > 8 ? 8 : n - 8 * g);
+            if (cnt > 0 && cnt < 8) ns[g] = (ns[g] >> (8 - cnt)) & (0x01010101u * ((1u << cnt) - 1u));
+            if (cnt == 0) ns[g] = 0;
+        }
+    }
+    /* the arg-min edge carries c1: its exact En replaces the as-if value pass 2 wrote (same lane, LDS operations in order) */
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lds.wr8(pa[k], enA >> (8 * k));
+
+    /* ---- the row's new compressed messages ---- */
+    SwRow out;
+    const int n = DEG > 0 ? DEG : deg;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int cnt = n - 8 * g < 0 ? 0 : (n - 8 * g > 8 ? 8 : n - 8 * g);
+        const uint32_t valid = 0x01010101u * ((1u << cnt) - 1u);
+        out.x[g] = ~(ns[g] ^ fm) & valid; /* negative iff not (nn ^ F) */
+    }
+    if (!MINSUM) {
+        /* A zero message has no sign: stored as "not negative" so that the next iteration's back-track reads
+         * "Lmn < 0" straight from the bit.  c2 == 0 zeroes every message of the row but the arg-min's. */
+        const uint32_t z2 = sw_zero_mask(c2n, sel_sign), nz1 = ~sw_zero_mask(c1n, sel_sign);
+        uint32_t oh[3] = { 0u, 0u, 0u };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ik = (idx >> (8 * k)) & 31u;
+            const uint32_t bit = 1u << ((ik & 7u) + 8u * (uint32_t)k);
+            oh[0] |= (ik >> 3) == 0u ? bit : 0u; oh[1] |= (ik >> 3) == 1u ? bit : 0u; oh[2] |= (ik >> 3) == 2u ? bit : 0u;
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) out.x[g] &= ~z2 | (oh[g] & nz1);
+    }
+    out.cw = c2n | (c1n << 3) | (negA & 0x40404040u);
+    out.pa[0] = pa[0] | (pa[1] << 16);
+    out.pa[1] = pa[2] | (pa[3] << 16);
+    return out;
+}
+
+#endif /* LNSFAID_SWAR_H */

@@ -18,6 +18,8 @@ void lnsfaid_oracle_destroy(lnsfaid_oracle* o);
 /* same buffers and layout as lnsfaid_decode() */
 int lnsfaid_oracle_decode(lnsfaid_oracle* o, const int8_t* fixInput, size_t n_groups, int8_t* decodedBits,
                           lnsfaid_group_stats* stats);
+/* test hook: n_iter layered iterations of one group without early stop, En per lane (en_out[l * N + v]) */
+int lnsfaid_oracle_layered_en(lnsfaid_oracle* o, const int8_t* fixInput, int n_iter, int8_t* en_out);
 int lnsfaid_oracle_count_errors(const lnsfaid_code* code, const int8_t* decodedBits, const int8_t* inputBits,
                                 size_t n_groups, uint64_t out[4]);
 

@@ -1,0 +1,109 @@
+/*
+ * swar_emul.cpp — TEST INFRASTRUCTURE: runs the product's 4-rows-per-lane layer step (csrc/lnsfaid_swar.h, the very
+ * statements the HIP kernel executes, compiled for the host with the ISA semantics of v_perm_b32 / v_alignbyte_b32 /
+ * v_bitop3_b32 restated in that header) lane by lane on the CPU, so that tests/ can compare it with the oracle's
+ * a-posteriori LLRs after every layered iteration without a GPU.  Never part of the product path.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "lnsfaid.h"
+#include "../mod-interleaveavx_multithreads-faid_amd/csrc/lnsfaid_swar.h"
+
+namespace {
+struct HostTab {
+    const uint32_t* row; /* sb of the layer's edges */
+    uint32_t sb(int j) const { return row[j]; }
+    uint32_t sb_dyn(uint32_t j) const { return row[j]; }
+};
+
+template <int METHOD>
+SwRow step(int deg, bool spec, const SwLds& lds, const HostTab& tab, const SwParams& p, uint32_t lane, SwRow cur, bool fresh,
+           uint32_t rowpar, bool lme)
+{
+    if (spec && deg == 23) return sw_layer_step<METHOD, 23>(lds, tab, p, lane, deg, cur, fresh, rowpar, lme);
+    if (spec && deg == 22) return sw_layer_step<METHOD, 22>(lds, tab, p, lane, deg, cur, fresh, rowpar, lme);
+    return sw_layer_step<METHOD, 0>(lds, tab, p, lane, deg, cur, fresh, rowpar, lme);
+}
+}
+
+/* n_iter layered iterations (no early stop) of every codeword of ONE group; en_out[l * N + v] = En of lane l.
+ * specialised != 0 uses the compile-time-degree instances for degrees 22 / 23 (what the kernel runs on the 50G-PON code). */
+extern "C" int swar_emul_layered(const lnsfaid_code* code, const lnsfaid_cfg* cfg, const int8_t* fixInput, int n_iter,
+                                 int specialised, int8_t* en_out)
+{
+    const int N = code->n_var, M = code->n_check, K = N - M, Z = code->z;
+    if (Z != 256) return LNSFAID_E_CODE;
+    const int nbr = M / Z;
+    std::vector<int> deg(nbr);
+    std::vector<uint32_t> sb((size_t)nbr * SW_MAX_DEG, 0u);
+    {
+        size_t e = 0; int r = 0;
+        std::vector<int> row_deg;
+        for (int k = 0; k < code->nb_degres; ++k) for (int i = 0; i < code->deg_rows[k]; ++i) row_deg.push_back(code->deg[k]);
+        for (int br = 0; br < nbr; ++br) {
+            deg[br] = row_deg[(size_t)br * Z];
+            if (deg[br] > SW_MAX_DEG) return LNSFAID_E_CODE;
+            for (int j = 0; j < deg[br]; ++j) sb[(size_t)br * SW_MAX_DEG + j] = code->pos_vn[e + j];
+            e += (size_t)deg[br] * Z; r += Z;
+        }
+    }
+    const int method = cfg->decode_method;
+    const bool oms = SW_OMS(method);
+    for (int l = 0; l < 32; ++l) {
+        std::vector<uint8_t> img((size_t)N + 4, 0);
+        for (int v = 0; v < N; ++v) {
+            int llr = v < K ? fixInput[(size_t)l * K + v] : fixInput[(size_t)32 * K + (size_t)l * M + (v - K)];
+            if (v >= N - code->puncture_tail) llr = 0;
+            img[sw_en_pos((uint32_t)v)] = (uint8_t)(llr + SW_BIAS_EN);
+        }
+        SwLds lds; lds.base = img.data();
+        std::vector<SwRow> rows((size_t)nbr * 64);
+        memset(rows.data(), 0, rows.size() * sizeof(SwRow));
+        for (int it = 1; it <= n_iter; ++it) {
+            /* syndrome stage: parity of every row and the (saturated) number of unsatisfied rows */
+            std::vector<uint8_t> par(M);
+            int unsat = 0;
+            {
+                size_t e = 0;
+                for (int r = 0; r < M; ++r) {
+                    const int d = deg[r / Z];
+                    int p = 0;
+                    for (int j = 0; j < d; ++j) p ^= ((int)img[sw_en_pos(code->pos_vn[e + j])] - SW_BIAS_EN) > 0;
+                    par[r] = (uint8_t)p; unsat += p; e += d;
+                }
+            }
+            const int rem = cfg->max_iteration - it;
+            bool lme;
+            if (oms) lme = (unsat > 255 ? 255 : unsat) < (int)(uint8_t)cfg->floor_err_count;
+            else lme = (unsat > 127 ? 127 : unsat) < (int)(int8_t)cfg->floor_err_count;
+            const int itx = (it >= 1 && it <= 5) ? it - 1 : 5;
+            SwParams p;
+            p.lut_lo = p.lut_hi = p.ef_lo = p.ef_hi = 0;
+            for (int a = 0; a < 8; ++a) {
+                (a < 4 ? p.lut_lo : p.lut_hi) |= (uint32_t)(uint8_t)cfg->v2c_map[itx][0][a] << (8 * (a & 3));
+                (a < 4 ? p.ef_lo : p.ef_hi) |= (uint32_t)(uint8_t)cfg->v2c_map_ef[itx][0][a] << (8 * (a & 3));
+            }
+            p.f1 = (int8_t)cfg->factor_1; p.f2 = (int8_t)cfg->factor_2;
+            p.window = rem <= cfg->floor_iter_thresh;
+            for (int br = 0; br < nbr; ++br) {
+                HostTab tab; tab.row = &sb[(size_t)br * SW_MAX_DEG];
+                for (uint32_t lane = 0; lane < 64; ++lane) {
+                    uint32_t rowpar = 0;
+                    for (int k = 0; k < 4; ++k) if (par[(size_t)br * Z + lane + 64 * k]) rowpar |= 0xffu << (8 * k);
+                    SwRow& cur = rows[(size_t)br * 64 + lane];
+                    const bool fresh = (it == 1);
+                    if (method == 2) cur = step<2>(deg[br], specialised != 0, lds, tab, p, lane, cur, fresh, rowpar, lme);
+                    else if (method == 5) cur = step<5>(deg[br], specialised != 0, lds, tab, p, lane, cur, fresh, rowpar, lme);
+                    else if (oms) cur = step<1>(deg[br], specialised != 0, lds, tab, p, lane, cur, fresh, rowpar, lme);
+                    else return LNSFAID_E_INVAL;
+                }
+            }
+        }
+        for (int v = 0; v < N; ++v) en_out[(size_t)l * N + v] = (int8_t)((int)img[sw_en_pos((uint32_t)v)] - SW_BIAS_EN);
+    }
+    return LNSFAID_OK;
+}
