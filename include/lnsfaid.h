@@ -226,6 +226,14 @@ int lnsfaid_host_unregister(void* ptr);
  * histogrammed into iterCount.txt by CSimulate.cpp:148-178) when the decoded frames themselves stay on the device. */
 int lnsfaid_read_stats(lnsfaid_ctx* ctx, lnsfaid_group_stats* stats, size_t n_groups);
 
+/* Which decode kernel the context launches.  rows_per_lane 0 (default): chosen per configuration - the byte-parallel kernel
+ * with four check rows per lane and one wavefront per codeword for DecodeMethods 1..5 with FAID tables that are uniform over
+ * the weight classes and non-decreasing (every set the reference ships), the two-rows-per-lane kernel otherwise (NMS, other
+ * tables); 2 / 4 force one of them (4: LNSFAID_E_INVAL where it does not apply).  Both produce identical results; the
+ * switch exists for tests and A/B timing.  lnsfaid_kernel_rows_per_lane returns what the next decode will launch. */
+int lnsfaid_select_kernel(lnsfaid_ctx* ctx, int32_t rows_per_lane);
+int lnsfaid_kernel_rows_per_lane(const lnsfaid_ctx* ctx);
+
 /* ---- measurement hooks ------------------------------------------------------- */
 
 /* Device time (HIP events on the context's stream) and launch count of the

@@ -17,6 +17,7 @@
 
 extern "C" hipError_t lf_launch_decode(int method, int uniform_w, const LfKernelArgs* args, size_t lds_bytes,
                                        hipStream_t stream);
+extern "C" hipError_t lf_launch_decode4(int method, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t lf_launch_count_errors(const int8_t* decoded, const int8_t* input_bits, int n_var, int k_info,
                                              size_t n_cw, unsigned long long* out, hipStream_t stream);
 
@@ -65,6 +66,7 @@ struct lnsfaid_ctx {
     int8_t* d_io_in = nullptr;
     int8_t* d_io_out = nullptr;
     lnsfaid_group_stats* d_io_stats = nullptr;
+    int rows_per_lane = 0; /* 0: pick per configuration; 2 / 4: forced (lnsfaid_select_kernel) */
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     /* device front-end scratch: seeds, draw counters, transmitted codeword */
@@ -107,6 +109,7 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
         out->deg[br] = deg;
         const uint16_t* row0 = code->pos_vn + e;
         for (int j = 0; j < 64; ++j) out->sbtab[br][j] = 0u;
+        for (int j = 0; j < 32; ++j) out->sbplain[br][j] = 0u;
         int prev_cb = -1;
         for (int j = 0; j < deg; ++j) {
             const int cb = row0[j] / Z, sh = row0[j] % Z;
@@ -114,6 +117,7 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
             prev_cb = cb;
             out->circ[br][j].sb = (uint32_t)cb * (uint32_t)Z + (uint32_t)sh;
             out->sbtab[br][LF_JCODE_A(j)] = out->sbtab[br][LF_JCODE_B(j)] = out->circ[br][j].sb;
+            out->sbplain[br][j] = out->circ[br][j].sb;
             if (out->col_weight[cb] >= LF_MAX_COLW) return LNSFAID_E_CODE;
             out->colcirc[cb][out->col_weight[cb]++] = (uint32_t)br | ((uint32_t)sh << 8);
         }
@@ -286,6 +290,8 @@ extern "C" int lnsfaid_create(lnsfaid_ctx** out, const lnsfaid_code* code, const
     if (!ctx) return LNSFAID_E_NOMEM;
     ctx->device = device;
     ctx->max_groups = max_groups;
+    if (const char* e = getenv("LNSFAID_ROWS_PER_LANE")) /* test / A-B switch: force the 2-rows-per-lane kernel for a whole run */
+        ctx->rows_per_lane = (e[0] == '2') ? 2 : 0;
     const int rc = create_impl(ctx, code, cfg);
     if (rc) { lnsfaid_destroy(ctx); return rc; }
     *out = ctx;
@@ -310,6 +316,32 @@ extern "C" int lnsfaid_set_cfg(lnsfaid_ctx* ctx, const lnsfaid_cfg* cfg)
 }
 
 /* ---- the hot path ------------------------------------------------------------------------------------ */
+/* The four-rows-per-lane kernel (lnsfaid_kernel4.hip) covers DecodeMethods 1..5 with FAID tables that are uniform over the
+ * weight classes and non-decreasing (OMS has no table) and needs max degree <= 24 like the other one; everything else, and
+ * NMS, runs on the two-rows-per-lane kernel. */
+static bool kernel4_possible(const lnsfaid_ctx* ctx)
+{
+    const int m = ctx->hcfg.method;
+    if (m < 1 || m > 5) return false;
+    if ((m == 2 || m == 5) && !ctx->hcfg.uniform_w) return false;
+    return true;
+}
+static bool use_kernel4(const lnsfaid_ctx* ctx)
+{
+    if (ctx->rows_per_lane == 2) return false;
+    return kernel4_possible(ctx);
+}
+
+extern "C" int lnsfaid_select_kernel(lnsfaid_ctx* ctx, int32_t rows_per_lane)
+{
+    if (!ctx || (rows_per_lane != 0 && rows_per_lane != 2 && rows_per_lane != 4)) return LNSFAID_E_INVAL;
+    if (rows_per_lane == 4 && !kernel4_possible(ctx)) return LNSFAID_E_INVAL;
+    ctx->rows_per_lane = rows_per_lane;
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_kernel_rows_per_lane(const lnsfaid_ctx* ctx) { return ctx ? (use_kernel4(ctx) ? 4 : 2) : LNSFAID_E_INVAL; }
+
 extern "C" int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput, size_t n_groups, int8_t* d_decodedBits,
                                      lnsfaid_group_stats* d_stats)
 {
@@ -336,7 +368,8 @@ extern "C" int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput,
         a.status_next = ctx->d_status[cur ^ 1];
         HIP_TRY(hipMemsetAsync(ctx->d_remaining, 0, sizeof(uint32_t), ctx->stream));
         HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-        HIP_TRY(lf_launch_decode(ctx->hcfg.method, ctx->hcfg.uniform_w, &a, ctx->lds_bytes, ctx->stream));
+        if (use_kernel4(ctx)) HIP_TRY(lf_launch_decode4(ctx->hcfg.method, &a, ctx->lds_bytes, ctx->stream));
+        else HIP_TRY(lf_launch_decode(ctx->hcfg.method, ctx->hcfg.uniform_w, &a, ctx->lds_bytes, ctx->stream));
         HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(hipMemcpyAsync(ctx->h_remaining, ctx->d_remaining, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -1,0 +1,331 @@
+/*
+ * lnsfaid_kernel4.hip — the decode kernel with ONE wavefront per codeword and four check rows per lane (gfx950).
+ *
+ * Same decoder, same group-of-32 protocol, same HBM state as lnsfaid_kernels.hip (see its header for the decision-point time
+ * line and the park / relaunch rules); what differs is how a layer is computed:
+ *   - lane i owns rows i, i + 64, i + 128, i + 192 of every layer; byte k of a working register belongs to row i + 64 k and
+ *     the layer step is carry-free byte-parallel arithmetic on plain 32-bit operations (lnsfaid_swar.h) instead of two rows on
+ *     packed 16-bit operations: ~1200 VALU instructions per layer of 256 rows, three quarters of them of the full-rate class,
+ *     against 2 x 615 with three quarters of the half-rate class;
+ *   - En is kept in LDS interleaved (variable node v of a block column in dword v mod 64, byte v div 64, biased by 120), so an
+ *     edge is one ds_read_b32 + one byte rotation for four rows, and a workgroup is a single wave: no barrier between layers;
+ *   - the compressed messages of a lane's four rows are 24 bytes per layer (SwRow).
+ * Used for DecodeMethods 1..5 whenever the FAID tables are uniform over the weight classes and non-decreasing (every shipped
+ * set); DecodeMethod 0 and other tables run on the two-rows-per-lane kernel.
+ */
+#include <hip/hip_runtime.h>
+
+#include "lnsfaid_device.h"
+#include "lnsfaid_phases.h"
+#include "lnsfaid_swar.h"
+
+#define LF_T4 64
+
+#define LF4_OMS(M) ((M) == 1 || (M) == 3 || (M) == 4)
+
+struct DevTab4 {
+    CCode c;
+    int br;
+    uint32_t sbv; /* lane j < 32: block column * 256 + shift of edge j of this layer */
+    __device__ __forceinline__ uint32_t sb(int j) const { return c->circ[br][j].sb; }
+    __device__ __forceinline__ uint32_t sb_dyn(uint32_t idx) const
+    {
+        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)sbv);
+    }
+};
+
+typedef __attribute__((address_space(3))) uint32_t lds4_u32;
+__device__ __forceinline__ uint32_t lds4_rd(uint32_t a) { return *(const lds4_u32*)(size_t)a; }
+__device__ __forceinline__ void lds4_wr(uint32_t a, uint32_t v) { *(lds4_u32*)(size_t)a = v; }
+
+/* hard decision En > 0 on the biased bytes (En + 120 >= 121): bit 7 of every byte of x + 7 */
+__device__ __forceinline__ uint32_t hard_flags(uint32_t x) { return x + 0x07070707u; }
+
+/* ---- bit plane from the interleaved En image: hard decision (CDecoder_FAID.cpp:299, :6416-6419) or, with CONF, the 2B1C
+ * confidence bit |En| >= thr (CDecoder_FAID_2B1C.cpp:6132-6136).  Lane d holds variable nodes d, d + 64, d + 128, d + 192 of a
+ * block column in one dword, so one ballot per byte gives 64 consecutive plane bits; the eight words of a column are
+ * gathered into lanes (v_writelane) and stored once per eight columns. */
+template <bool CONF>
+__device__ void build_plane4(CCode c, uint32_t* plane, int thr, int lane)
+{
+    const int nbc = c->nbc;
+    const int th = thr < 1 ? 0 : (thr > 32 ? 32 : thr); /* |En| <= 31: a threshold above 31 means "never" */
+    const uint32_t th4 = (uint32_t)th * 0x01010101u;
+    const uint32_t b8 = (uint32_t)(128 - SW_BIAS_EN) * 0x01010101u, b7 = (uint32_t)(127 - SW_BIAS_EN) * 0x01010101u;
+    for (int cb0 = 0; cb0 < nbc; cb0 += 8) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int cb = cb0 + u;
+            if (cb < nbc) { /* uniform */
+                const uint32_t x = lds4_rd((uint32_t)cb * 256u + 4u * (uint32_t)lane);
+                uint32_t fl;
+                /* En >= thr  <=>  Eb + 8 - thr >= 128;  En <= -thr  <=>  Eb + 7 + thr < 128 (no carries: Eb in [89, 151]) */
+                if (CONF) fl = th == 0 ? 0x80808080u : (((x + b8) - th4) | ~(x + b7 + th4));
+                else fl = hard_flags(x);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long m = __ballot((fl >> (8 * k + 7)) & 1u);
+                    /* gfx940+: a VALU that reads an SGPR written by the VALU just before it (the compare behind __ballot)
+                     * needs two wait states; the compiler does not look inside inline assembly, so they are spelled out */
+                    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2\n\tv_writelane_b32 %0, %3, %4"
+                                 : "+v"(w) : "s"((uint32_t)m), "n"(8 * u + 2 * k), "s"((uint32_t)(m >> 32)), "n"(8 * u + 2 * k + 1));
+                }
+            }
+        }
+        if (cb0 * 8 + lane < nbc * 8) plane[cb0 * 8 + lane] = w;
+    }
+    __syncthreads();
+}
+
+/* ---- cheap "certainly dirty" test (DecodeMethod 2, see lnsfaid_kernels.hip): parity of the lane's four rows of layer 0
+ * straight from En; the XOR of the hard-decision flags is bit 7 of the XOR of the flag words. */
+__device__ bool layer0_dirty4(CCode c, int lane)
+{
+    const int deg = c->deg[0];
+    const uint32_t tid4 = (uint32_t)lane << 2;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < LF_MAX_DEG; ++j) {
+        if (j < deg) {
+            const uint32_t sb = c->circ[0][j].sb;
+            const uint32_t x4 = tid4 + ((sb & 255u) << 2);
+            const uint32_t d = lds4_rd((x4 & 0xfcu) | (sb & ~255u));
+            acc ^= hard_flags(__builtin_amdgcn_alignbyte(d, d, x4 >> 8));
+        }
+    }
+    return __ballot((acc & 0x80808080u) != 0u) != 0ull;
+}
+
+/* ---- one layered iteration (lnsfaid_swar.h does the rows) ---- */
+template <int METHOD>
+__device__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, SwRow* __restrict__ rows, int lane, int it, const uint32_t* sP,
+                           bool have_par, bool lme)
+{
+    const bool fresh = (it == 1); /* no iteration has run yet: every Lmn is still 0, nothing in HBM */
+    const int rem = f->max_iter - it;
+    const int itx = (it >= 1 && it <= 5) ? it - 1 : 5; /* switch at CDecoder_FAID.cpp:760-779 */
+    SwParams p;
+    p.lut_lo = f->lut_lo[itx][0]; p.lut_hi = f->lut_hi[itx][0];
+    p.ef_lo = f->lut_ef_lo[itx][0]; p.ef_hi = f->lut_ef_hi[itx][0];
+    p.f1 = f->factor_1; p.f2 = f->factor_2;
+    p.window = rem <= f->floor_iter_thresh;
+    const int nbr = c->nbr;
+    const SwLds lds = SwLds();
+    const SwRow zero = { { 0u, 0u, 0u }, 0u, { 0u, 0u } }; /* Lmn = 0 before the first iteration (CDecoder_FAID.cpp:211-214) */
+    SwRow cur = zero;
+    if (!fresh) cur = rows[lane];
+    uint32_t tabv = gc->sbplain[0][lane & 31];
+    for (int br = 0; br < nbr; ++br) {
+        /* next layer's messages and edge table: issued a whole layer ahead of their use; always a valid address (the last
+         * layer re-reads layer 0, the first iteration reads what it is about to overwrite and ignores it) */
+        const int brn = br + 1 < nbr ? br + 1 : 0;
+        const SwRow nxt = rows[brn * LF_T4 + lane];
+        const uint32_t tabn = gc->sbplain[brn][lane & 31];
+        const int deg = c->deg[br];
+        uint32_t rowpar = 0;
+        if (have_par) { /* syndrome bits of rows lane + 64 k of this layer as byte masks */
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t wv = sP[br * 8 + 2 * k + (lane >> 5)];
+                rowpar |= ((wv >> (lane & 31)) & 1u) ? (0xffu << (8 * k)) : 0u;
+            }
+        }
+        DevTab4 tab;
+        tab.c = c; tab.br = br; tab.sbv = tabv;
+        SwRow st;
+        if (deg == 23) st = sw_layer_step<METHOD, 23>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
+        else if (deg == 22) st = sw_layer_step<METHOD, 22>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
+        else st = sw_layer_step<METHOD, 0>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
+        if (rem > 0) rows[br * LF_T4 + lane] = st; /* the last layered iteration's messages are never read again */
+        cur = fresh ? zero : nxt;
+        tabv = tabn;
+    }
+}
+
+/* ---- the decode kernel: one wave per codeword ---------------------------------------------------------- */
+template <int METHOD>
+__global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    CCode c = (CCode)a.code;
+    CCfg f = (CCfg)a.cfg;
+    const int tid = (int)threadIdx.x;
+    const int cw = (int)blockIdx.x;
+    const int N = c->n_var, M = c->n_check, K = c->k_info, nw = c->n_words, pw = c->p_words;
+    {   /* the layer step addresses En by its LDS offset: the dynamic segment must start at 0 */
+        uint32_t en_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+        asm volatile("" : "+s"(en_base));
+        if (en_base != 0u) __builtin_trap();
+    }
+    uint32_t* sHard0 = (uint32_t*)smem;      /* bit-flipping stage: hard_ch and hard2 overlay the dead En */
+    uint32_t* sHard2 = (uint32_t*)smem + nw;
+    uint32_t* sHard = (uint32_t*)(smem + lf_lds_off_hard(N));
+    uint32_t* sP = (uint32_t*)(smem + lf_lds_off_p(N, nw));
+    int* sStat = (int*)(smem + lf_lds_off_stat(N, nw, pw));
+    int* sRed = sStat + LNSFAID_GROUP;
+
+    const int max_iter = f->max_iter, max_bf = f->max_bf;
+    const int t_bf0 = max_iter + 1;   /* first bit-flipping decision point */
+    const int t_end = t_bf0 + max_bf; /* both loops exhausted               */
+
+    const int my_status = a.status_cur[cw];
+    if (my_status & LF_DONE) { /* uniform exit */
+        if (tid == 0) a.status_next[cw] = my_status;
+        return;
+    }
+    /* snapshot of the 32 lanes of this group */
+    const int g = cw >> 5, lane_in_group = cw & 31;
+    if (tid < LNSFAID_GROUP) sStat[tid] = a.status_cur[g * LNSFAID_GROUP + tid];
+    if (tid == LNSFAID_GROUP) sRed[LF_ZERO_SLOT] = 0; /* the word unused synw slots point at */
+    __syncthreads();
+    int kmax = 0, all_same = 1;
+    for (int l = 0; l < LNSFAID_GROUP; ++l) {
+        const int s = sStat[l];
+        kmax = imax(kmax, s & LF_PROG_MASK);
+        all_same &= (s == my_status);
+    }
+    int prog = my_status & LF_PROG_MASK;
+
+    uint32_t* g_en = (uint32_t*)(a.st_en + (size_t)cw * (size_t)N);
+    SwRow* g_rows = (SwRow*)(a.st_rows + (size_t)cw * (size_t)(c->nbr * LF_T)); /* the 2-row kernel's slot: 16 B x 128 >= 24 B x 64 */
+    uint32_t* g_bits = a.st_bits + (size_t)cw * (size_t)(3 * nw);
+    int8_t* g_out = a.decoded + (size_t)cw * (size_t)N;
+
+    /* parked on the group's front, not everybody there yet: nothing to do in this launch */
+    if (prog != 0 && prog == kmax && !all_same) {
+        if (tid == 0) { a.status_next[cw] = my_status; atomicAdd(a.remaining, 1u); }
+        return;
+    }
+
+    bool in_bf = max_bf > 0 && prog >= t_bf0 && prog != 0;
+    LfLaneState ls = { 0, 0, 0, 0 };
+
+    /* ---- bring the codeword's state on chip ---- */
+    if (prog == 0) {
+        /* input staging (CDecoder_FAID.cpp:217-255): lane l of group g is information row l of the [32][K] block followed by
+         * parity row l of the [32][M] block; punctured tail erased; interleaved and biased for the layer step */
+        const int8_t* gi = a.fix_input + (size_t)g * (size_t)LNSFAID_GROUP * (size_t)N;
+        const int8_t* src_i = gi + (size_t)lane_in_group * (size_t)K;
+        const int8_t* src_p = gi + (size_t)LNSFAID_GROUP * (size_t)K + (size_t)lane_in_group * (size_t)M;
+        const int first_erased = N - c->puncture_tail;
+        for (int cb = 0; cb < c->nbc; ++cb) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v = cb * LF_Z + tid + 64 * k;
+                int x = v < K ? src_i[v] : src_p[v - K];
+                if (v >= first_erased) x = 0;
+                w |= (uint32_t)((x + SW_BIAS_EN) & 0xff) << (8 * k);
+            }
+            lds4_wr((uint32_t)cb * 256u + 4u * (uint32_t)tid, w);
+        }
+        __syncthreads();
+        prog = 1;
+    } else if (!in_bf) {
+        uint32_t* dst = (uint32_t*)smem;
+        for (int i = tid; i < (N >> 2); i += LF_T4) dst[i] = g_en[i];
+        __syncthreads();
+    } else {
+        for (int i = tid; i < nw; i += LF_T4) { sHard[i] = g_bits[i]; sHard0[i] = g_bits[nw + i]; sHard2[i] = g_bits[2 * nw + i]; }
+        ls = a.st_lane[cw];
+        __syncthreads();
+    }
+
+    /* ---- all 32 lanes parked clean at the same decision point: the group stops here ---- */
+    const bool group_stop = (my_status != 0) && all_same;
+
+    if (!group_stop) {
+        for (;;) {
+            if (prog >= t_end) break; /* loops exhausted (also OMS after max_iter iterations) */
+            if (max_bf > 0 && prog >= t_bf0 && !in_bf) {
+                /* the layered loop ran out: enter the bit-flipping stage (CDecoder_FAID.cpp:6411-6428) */
+                uint32_t conf[LF_MAX_BC * 8 / LF_T4]; /* this lane's share of the 2B1C confidence plane */
+                if (METHOD == 5) {
+                    build_plane4<true>(c, sHard, f->hard2_thr, tid); /* staged where the hard plane will go */
+#pragma unroll
+                    for (int k = 0; k < LF_MAX_BC * 8 / LF_T4; ++k) conf[k] = (tid + k * LF_T4 < nw) ? sHard[tid + k * LF_T4] : 0u;
+                    __syncthreads();
+                }
+                build_plane4<false>(c, sHard, 0, tid);
+                /* En is dead from here on: its bytes take hard_ch (= hard) and hard2 */
+                for (int i = tid; i < nw; i += LF_T4) sHard0[i] = sHard[i];
+                if (METHOD == 5) {
+#pragma unroll
+                    for (int k = 0; k < LF_MAX_BC * 8 / LF_T4; ++k) if (tid + k * LF_T4 < nw) sHard2[tid + k * LF_T4] = conf[k];
+                }
+                ls.Th = (int8_t)f->W; ls.l0 = 0; ls.l1 = 0; ls.t = 1;
+                in_bf = true;
+                __syncthreads();
+            }
+            uint32_t pA = 0, pB = 0;
+            if (!in_bf) {
+                bool lme = false, have_par = false;
+                /* l_checksum_ and the unsatisfied count are consumed only inside the error-floor window
+                 * (nombre_iterations <= floor_iter_thresh: OMS selective offset CDecoder_OMS.cpp:388, 2B1C tables
+                 * CDecoder_FAID.cpp:714) and never by DecodeMethod 2; elsewhere only unsat != 0 matters */
+                const bool needs_checksums = (METHOD != 2) && (max_iter - prog <= f->floor_iter_thresh);
+                if (needs_checksums || !layer0_dirty4(c, tid)) {
+                    build_plane4<false>(c, sHard, 0, tid);
+                    const int unsat = syndrome<LF_T4, false>(c, a.code, sP, tid, pA, pB, sRed);
+                    if (unsat == 0 && prog >= kmax) break; /* clean on the group's front: park */
+                    if (LF4_OMS(METHOD)) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
+                    else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
+                    have_par = true;
+                }
+                main_step4<METHOD>(c, f, a.code, g_rows, tid, prog, sP, have_par && needs_checksums, lme);
+                prog++;
+            } else {
+                const int unsat = syndrome<LF_T4, false>(c, a.code, sP, tid, pA, pB, sRed);
+                if (unsat == 0 && prog >= kmax) break;
+                if (METHOD == 3) bf_step_plain<LF_T4>(c, f, a.code, sHard, sHard2 + nw /* 4 count planes in the dead En */, sP, tid, sRed);
+                else bf_step<LF_T4, METHOD>(c, f, a.code, sHard, sHard0, sHard2, sP, tid, ls, sRed);
+                prog++;
+            }
+        }
+    }
+
+    const bool finished = group_stop || prog >= t_end;
+    if (finished) {
+        /* decodedBits[l][v] = hard decision (CDecoder_FAID.cpp:7091-7102, CDecoder_OMS.cpp:2966-2967) */
+        if (!in_bf) build_plane4<false>(c, sHard, 0, tid);
+        uint32_t* out32 = (uint32_t*)g_out;
+        for (int i = tid; i < (N >> 2); i += LF_T4) {
+            const uint32_t bits = (sHard[i >> 3] >> ((i & 7) * 4)) & 15u;
+            out32[i] = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
+        }
+        if (tid == 0) {
+            a.status_next[cw] = prog | LF_DONE;
+            if (a.stats && lane_in_group == 0) {
+                lnsfaid_group_stats st;
+                st.iterations = prog <= max_iter ? prog - 1 : max_iter;
+                st.bf_iterations = prog <= max_iter ? 0 : prog - t_bf0;
+                a.stats[g] = st;
+            }
+        }
+    } else {
+        /* park: state back to HBM, status = the decision point the codeword is clean at */
+        if (!in_bf) {
+            const uint32_t* src = (const uint32_t*)smem;
+            for (int i = tid; i < (N >> 2); i += LF_T4) g_en[i] = src[i];
+        } else {
+            for (int i = tid; i < nw; i += LF_T4) { g_bits[i] = sHard[i]; g_bits[nw + i] = sHard0[i]; g_bits[2 * nw + i] = sHard2[i]; }
+            if (tid == 0) a.st_lane[cw] = ls;
+        }
+        if (tid == 0) { a.status_next[cw] = prog; atomicAdd(a.remaining, 1u); }
+    }
+}
+
+extern "C" hipError_t lf_launch_decode4(int method, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream)
+{
+    const dim3 grid((unsigned)args->n_cw), block(LF_T4);
+    switch (method) {
+    case 1: hipLaunchKernelGGL((lnsfaid_decode4_kernel<1>), grid, block, lds_bytes, stream, *args); break;
+    case 2: hipLaunchKernelGGL((lnsfaid_decode4_kernel<2>), grid, block, lds_bytes, stream, *args); break;
+    case 3: hipLaunchKernelGGL((lnsfaid_decode4_kernel<3>), grid, block, lds_bytes, stream, *args); break;
+    case 4: hipLaunchKernelGGL((lnsfaid_decode4_kernel<4>), grid, block, lds_bytes, stream, *args); break;
+    case 5: hipLaunchKernelGGL((lnsfaid_decode4_kernel<5>), grid, block, lds_bytes, stream, *args); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

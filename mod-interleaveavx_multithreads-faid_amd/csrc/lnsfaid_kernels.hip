@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 
 #include "lnsfaid_device.h"
+#include "lnsfaid_phases.h"
 
 /* DecodeMethods whose layered loop is Decode_OMS's: 1 (alone), 3 (+ plain bit flipping), 4 (+ DTBF) */
 #define LF_OMS(M) ((M) == 1 || (M) == 3 || (M) == 4)
@@ -46,9 +47,6 @@
 #define SAT_NEG_VAR (-31)
 #define SAT_POS_MSG 7  /* Constants_SSE.h:24 */
 
-/* tables are read through the constant address space so that uniform accesses become scalar loads */
-typedef const __attribute__((address_space(4))) LfDevCode* CCode;
-typedef const __attribute__((address_space(4))) LfDevCfg* CCfg;
 
 typedef short s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u2 __attribute__((ext_vector_type(2)));
@@ -120,19 +118,6 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b)
     return r;
 }
 
-__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
-__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
-
-/* sum of a wave-uniform per-wave value over the 2 waves of the workgroup */
-__device__ __forceinline__ int block_sum2(int wave_value, int tid, int* sRed)
-{
-    if ((tid & 63) == 0) sRed[tid >> 6] = wave_value;
-    __syncthreads();
-    const int total = sRed[0] + sRed[1];
-    __syncthreads();
-    return total;
-}
-
 /* XOR over lanes 0..31 of a wave half, result in lane 31 (DPP row shifts + row broadcast, no LDS) */
 __device__ __forceinline__ uint32_t xor_reduce32(uint32_t v)
 {
@@ -142,15 +127,6 @@ __device__ __forceinline__ uint32_t xor_reduce32(uint32_t v)
     v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
     v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1, 3 */
     return v;
-}
-
-/* 64 bits starting at bit `o` (mod 256) of a 256-bit block kept as 8 LDS words */
-__device__ __forceinline__ void window64(const uint32_t* blk, uint32_t o, uint32_t& lo, uint32_t& hi)
-{
-    const uint32_t q = o >> 5, r = o & 31u;
-    const uint32_t w0 = blk[q & 7u], w1 = blk[(q + 1u) & 7u], w2 = blk[(q + 2u) & 7u];
-    lo = __builtin_amdgcn_alignbit(w1, w0, r);
-    hi = __builtin_amdgcn_alignbit(w2, w1, r);
 }
 
 /* ---- bit plane from En: hard decision En > 0 (CDecoder_FAID.cpp:299, :6416-6419), or with CONF the 2B1C
@@ -194,58 +170,6 @@ __device__ void build_plane(CCode c, const int8_t* sEn, uint32_t* plane, int thr
     __syncthreads();
 }
 
-/* sum over lanes 0..31 / 32..63 of a wave, results in lanes 31 / 63 (same DPP pattern as xor_reduce32) */
-__device__ __forceinline__ int add_reduce32(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1, 3 */
-    return v;
-}
-
-/* ---- bit-parallel syndrome of the hard-decision plane sHard (CDecoder_FAID.cpp:291-343, :6443-6491) -----------
- * The parity of the 32 rows [32k, 32k+32) of layer br is the XOR over the row's circulants of 32 consecutive (mod 256)
- * bits of the circulant's block column.  One lane per (layer, k): it walks the layer's circulants with a host-built
- * table of {LDS addresses of the two plane words, bit offset} (LfDevCode::synw), two ds_read_b32 + one v_alignbit_b32
- * + one v_xor per circulant and no cross-lane reduction; slots beyond the row degree point at a zero word.
- * Writes the parity plane sP (bit r = l_checksum_[r]), returns the number of unsatisfied checks; with ROWBITS pA / pB
- * get bit br = parity of this thread's rows tid / tid + 128 in layer br (the error-floor tables need them). */
-template <bool ROWBITS>
-__device__ int syndrome(CCode c, const LfDevCode* gc, uint32_t* sP, int tid, uint32_t& pA, uint32_t& pB, int* sRed)
-{
-    typedef const __attribute__((address_space(3))) uint32_t lds_u32;
-    const int nbr = c->nbr;
-    int cnt = 0;
-    for (int task = tid; task < nbr * 8; task += LF_T) {
-        const uint2* tab = &gc->synw[task >> 3][0][task & 7];
-        uint32_t acc = 0;
-#pragma unroll
-        for (int j = 0; j < LF_MAX_DEG; ++j) {
-            const uint2 e = tab[j * 8];
-            const uint32_t w0 = *(lds_u32*)(size_t)(e.x & 0xffffu), w1 = *(lds_u32*)(size_t)(e.x >> 16);
-            acc ^= __builtin_amdgcn_alignbit(w1, w0, e.y);
-        }
-        sP[task] = acc;
-        cnt += __popc(acc);
-    }
-    cnt = add_reduce32(cnt);
-    const int wave_cnt = __builtin_amdgcn_readlane(cnt, 31) + __builtin_amdgcn_readlane(cnt, 63);
-    const int total = block_sum2(wave_cnt, tid, sRed); /* its barriers also publish sP */
-    if (ROWBITS) {
-        uint32_t a = 0, b = 0;
-        const uint32_t* p = sP + (tid >> 5);
-        const uint32_t sh = (uint32_t)tid & 31u;
-        for (int br = 0; br < nbr; ++br) {
-            a |= ((p[br * 8] >> sh) & 1u) << br;
-            b |= ((p[br * 8 + 4] >> sh) & 1u) << br;
-        }
-        pA = a; pB = b;
-    }
-    return total;
-}
-
 /* ---- cheap "certainly dirty" test for decoders that only need unsat != 0 (DecodeMethod 2: no EF tables, no
  * selective offset): parity of this thread's two rows of layer 0 straight from En.  The hard decision En > 0
  * is the sign bit of -En, and the XOR of the sign bits is the sign bit of the XOR.  A non-zero parity anywhere
@@ -270,7 +194,7 @@ __device__ bool layer0_dirty(CCode c, const int8_t* sEn, int tid, uint32_t vff, 
         }
         dirty = __ballot((accA | accB) < 0) != 0ull ? 1 : 0;
     }
-    return block_sum2(dirty, tid, sRed) != 0;
+    return block_sum<LF_T>(dirty, tid, sRed) != 0;
 }
 
 /* selective offset of OMS_MODE 1 on one minimum (CDecoder_OMS.cpp:388-425); all operands are int8 in the
@@ -590,172 +514,6 @@ __device__ void main_step(CCode c, CCfg f, const LfDevCode* gc, int8_t* sEn, uin
     }
 }
 
-/* ---- bit-flipping iteration after a dirty syndrome (CDecoder_FAID.cpp:6787-6845, :7084-7086;
- *      CDecoder_FAID_2B1C.cpp:6801-6814) --------------------------------------------------------------- */
-__device__ __forceinline__ int bit_of(const uint32_t* words, int v) { return (int)((words[v >> 5] >> (v & 31)) & 1u); }
-
-template <int METHOD>
-__device__ void bf_step(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, const uint32_t* sHard0, uint32_t* sHard2,
-                        const uint32_t* sP, int tid, LfLaneState& ls, int* sRed)
-{
-    const int W = f->W;
-    /* threshold state machine on int8 lanes (CDecoder_FAID.cpp:6787-6799) */
-    int Th = ls.Th, l0 = ls.l0, l1 = ls.l1;
-    if (!ls.t) Th = imax(Th - f->delta, -128);
-    const bool max_Th = ls.t && (l0 < (int)(int8_t)f->L0);
-    if (max_Th) { Th = (int8_t)(W + f->alpha); l0 = imin(l0 + 1, 127); }
-    const bool submax_Th = ls.t && !max_Th && (l1 < (int)(int8_t)f->L1);
-    if (submax_Th) { Th = (int8_t)(W + f->alpha - f->delta); l1 = imin(l1 + 1, 127); }
-    if (ls.t && !max_Th && !submax_Th) Th = (int8_t)(W + f->alpha - 2 * f->delta);
-    Th = imax(Th, 1);
-    const bool big = Th >= (int)(int8_t)W; /* mask_big_jump, 2B1C only */
-    const int alpha = (int8_t)f->alpha;
-    int any = 0;
-
-    if (f->bf_fast) {
-        /* bit-sliced: one (weight-3 block column, 64-VN window) per lane */
-        const int units = c->n_wcols * 4;
-        for (int u = tid; u < units; u += LF_T) {
-            const int cb = gc->wcol[u >> 2];
-            const uint32_t win = (uint32_t)(u & 3);
-            uint32_t plo[3], phi[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const uint32_t cc = gc->colcirc[cb][k];
-                window64(sP + (cc & 0xffu) * 8u, (64u * win - ((cc >> 8) & 0xffu)) & 255u, plo[k], phi[k]);
-            }
-            const int w0 = cb * 8 + 2 * (int)win;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t p1 = h ? phi[0] : plo[0], p2 = h ? phi[1] : plo[1], p3 = h ? phi[2] : plo[2];
-                const uint32_t hd = sHard[w0 + h];
-                const uint32_t fl = alpha ? (hd ^ sHard0[w0 + h]) : 0u; /* already flipped once: +alpha */
-                const uint32_t s0 = p1 ^ p2 ^ p3, cy = (p1 & p2) | (p1 & p3) | (p2 & p3);
-                uint32_t m;
-                if (Th <= 1) m = s0 | cy | fl;          /* votes + fl >= 1 */
-                else if (Th == 2) m = cy | (s0 & fl);
-                else if (Th == 3) m = cy & (s0 | fl);
-                else if (Th == 4) m = cy & s0 & fl;
-                else m = 0u;
-                any |= (m != 0u);
-                if (METHOD == 5) {
-                    const uint32_t h2 = sHard2[w0 + h];
-                    if (big) { sHard[w0 + h] = hd ^ m; sHard2[w0 + h] = h2 ^ m; }
-                    else { sHard[w0 + h] = hd ^ (m & ~h2); sHard2[w0 + h] = h2 & ~m; }
-                } else {
-                    sHard[w0 + h] = hd ^ m;
-                }
-            }
-        }
-    } else {
-        /* generic column weight / alpha: one variable node per lane and step */
-        const int nbc = c->nbc;
-        for (int cb = 0; cb < nbc; ++cb) {
-            if (c->col_weight[cb] != W) continue; /* VN_weight_[v] == REGULAR_COL_WEIGHT, :6806 */
-            for (int half = 0; half < 2; ++half) {
-                const int x = tid + half * LF_T;
-                const int v = cb * LF_Z + x;
-                int vote = 0;
-                for (int k = 0; k < W; ++k) {
-                    const uint32_t cc = gc->colcirc[cb][k];
-                    vote += bit_of(sP, (int)((cc & 0xffu) << 8) + (int)(((uint32_t)x - ((cc >> 8) & 0xffu)) & 0xffu));
-                }
-                const int flipped = bit_of(sHard, v) ^ bit_of(sHard0, v);
-                const int fl = (imin(vote + (flipped ? alpha : 0), 127) >= Th) ? 1 : 0;
-                const unsigned long long fm = __ballot(fl);
-                any |= (fm != 0ull);
-                if ((tid & 63) == 0) {
-                    const int w = v >> 5;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const uint32_t m = (uint32_t)(fm >> (32 * h));
-                        if (METHOD == 5) {
-                            const uint32_t h2 = sHard2[w + h];
-                            if (big) { sHard[w + h] ^= m; sHard2[w + h] = h2 ^ m; }
-                            else { sHard[w + h] ^= m & ~h2; sHard2[w + h] = h2 & ~m; }
-                        } else {
-                            sHard[w + h] ^= m;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    ls.Th = Th; ls.l0 = l0; ls.l1 = l1;
-    const unsigned long long anyw = __ballot(any);
-    ls.t = block_sum2(anyw != 0ull ? 1 : 0, tid, sRed) != 0; /* barriers also order the plane updates */
-}
-
-/* ---- plain bit flipping of Decode_OMSBF (CDecoder_OMSBF.cpp:2969-3514): flip every variable node whose vote count
- * reaches min(max vote of the frame, cap).  Votes of all block columns are counted bit-sliced (4 planes, column
- * weight <= 15), the frame's maximum is found from "some count >= k" flags, then the planes are compared with the
- * threshold. */
-__device__ __forceinline__ uint32_t votes_ge(uint32_t c3, uint32_t c2, uint32_t c1, uint32_t c0, int k)
-{
-    /* bitwise 4-bit comparator: count < k, scanned from the most significant plane */
-    uint32_t lt = 0u, eqm = 0xffffffffu;
-    const uint32_t pl[4] = { c0, c1, c2, c3 };
-#pragma unroll
-    for (int b = 3; b >= 0; --b) {
-        if ((k >> b) & 1) { lt |= eqm & ~pl[b]; eqm &= pl[b]; }
-        else eqm &= ~pl[b];
-    }
-    return ~lt;
-}
-
-__device__ void bf_step_plain(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, uint32_t* sCnt, const uint32_t* sP, int tid,
-                              int* sRed)
-{
-    const int nw = c->n_words;
-    const int units = c->nbc * 4;
-    uint32_t seen = 0; /* bit k: some variable node of this lane's units has >= k votes (k = 1..15) */
-    for (int u = tid; u < units; u += LF_T) {
-        const int cb = u >> 2;
-        const uint32_t win = (uint32_t)(u & 3);
-        const int wgt = gc->col_weight[cb];
-        uint32_t c0[2] = { 0u, 0u }, c1[2] = { 0u, 0u }, c2[2] = { 0u, 0u }, c3[2] = { 0u, 0u };
-        for (int k = 0; k < wgt; ++k) {
-            const uint32_t cc = gc->colcirc[cb][k];
-            uint32_t x[2];
-            window64(sP + (cc & 0xffu) * 8u, (64u * win - ((cc >> 8) & 0xffu)) & 255u, x[0], x[1]);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) { /* ripple-carry increment of the 4-bit counters where x is set */
-                uint32_t carry = x[h], t;
-                t = c0[h] & carry; c0[h] ^= carry; carry = t;
-                t = c1[h] & carry; c1[h] ^= carry; carry = t;
-                t = c2[h] & carry; c2[h] ^= carry; carry = t;
-                c3[h] ^= carry;
-            }
-        }
-        const int w0 = cb * 8 + 2 * (int)win;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            sCnt[w0 + h] = c0[h]; sCnt[nw + w0 + h] = c1[h]; sCnt[2 * nw + w0 + h] = c2[h]; sCnt[3 * nw + w0 + h] = c3[h];
-#pragma unroll
-            for (int k = 1; k < 16; ++k) seen |= (votes_ge(c3[h], c2[h], c1[h], c0[h], k) != 0u) ? (1u << k) : 0u;
-        }
-    }
-    /* OR of `seen` over the workgroup */
-    for (int o = 32; o > 0; o >>= 1) seen |= (uint32_t)__shfl_xor((int)seen, o);
-    if ((tid & 63) == 0) sRed[tid >> 6] = (int)seen;
-    __syncthreads();
-    seen = (uint32_t)sRed[0] | (uint32_t)sRed[1];
-    __syncthreads();
-    const int max_vote = seen ? 31 - __clz((int)seen) : 1; /* max_vote starts at 1 (CDecoder_OMSBF.cpp:2975) */
-    const int thr = imin(imax(max_vote, 1), (int)(int8_t)f->vote_cap);
-    for (int u = tid; u < units; u += LF_T) {
-        const int w0 = (u >> 2) * 8 + 2 * (u & 3);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            uint32_t m = 0xffffffffu; /* thr <= 0: every vote count qualifies */
-            if (thr >= 16) m = 0u;
-            else if (thr > 0) m = votes_ge(sCnt[3 * nw + w0 + h], sCnt[2 * nw + w0 + h], sCnt[nw + w0 + h], sCnt[w0 + h], thr);
-            sHard[w0 + h] ^= m;
-        }
-    }
-    __syncthreads();
-}
-
 /* ---- the decode kernel: one workgroup per codeword ---------------------------------------------------- */
 template <int METHOD, bool UNIW>
 __global__ __launch_bounds__(LF_T, LF_WAVES_PER_SIMD) void lnsfaid_decode_kernel(LfKernelArgs a)
@@ -880,7 +638,7 @@ __global__ __launch_bounds__(LF_T, LF_WAVES_PER_SIMD) void lnsfaid_decode_kernel
                 const bool needs_checksums = (METHOD != 2) && (max_iter - prog <= f->floor_iter_thresh);
                 if (needs_checksums || !layer0_dirty(c, sEn, tid, vff0, sRed)) {
                     build_plane<false>(c, sEn, sHard, 0, tid);
-                    const int unsat = syndrome<true>(c, a.code, sP, tid, pA, pB, sRed);
+                    const int unsat = syndrome<LF_T, true>(c, a.code, sP, tid, pA, pB, sRed);
                     if (unsat == 0 && prog >= kmax) break; /* clean on the group's front: park */
                     if (LF_OMS(METHOD)) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
                     else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
@@ -888,10 +646,10 @@ __global__ __launch_bounds__(LF_T, LF_WAVES_PER_SIMD) void lnsfaid_decode_kernel
                 main_step<METHOD, UNIW>(c, f, a.code, sEn, g_rows, tid, prog, pA, pB, lme);
                 prog++;
             } else {
-                const int unsat = syndrome<false>(c, a.code, sP, tid, pA, pB, sRed);
+                const int unsat = syndrome<LF_T, false>(c, a.code, sP, tid, pA, pB, sRed);
                 if (unsat == 0 && prog >= kmax) break;
-                if (METHOD == 3) bf_step_plain(c, f, a.code, sHard, sHard2 + nw /* 4 count planes in the dead En */, sP, tid, sRed);
-                else bf_step<METHOD>(c, f, a.code, sHard, sHard0, sHard2, sP, tid, ls, sRed);
+                if (METHOD == 3) bf_step_plain<LF_T>(c, f, a.code, sHard, sHard2 + nw /* 4 count planes in the dead En */, sP, tid, sRed);
+                else bf_step<LF_T, METHOD>(c, f, a.code, sHard, sHard0, sHard2, sP, tid, ls, sRed);
                 prog++;
             }
         }

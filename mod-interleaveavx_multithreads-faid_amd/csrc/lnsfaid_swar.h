@@ -34,7 +34,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIPCC__) /* both passes of hipcc see the device flavour; a plain C++ compiler gets the restatements */
 #define SW_DEV 1
 #define SW_FN __device__ __forceinline__
 #else
@@ -43,6 +43,15 @@
 #endif
 
 #define SW_MAX_DEG 24
+
+/* Keeps the compiler's scheduler from moving instructions across this point.  With two waves per SIMD nothing hides an LDS
+ * round trip, so the layer step issues all loads of a phase back to back and only then starts consuming them; left alone the
+ * scheduler interleaves "load, wait, use" per edge (one read in flight, every LDS latency exposed). */
+#if SW_DEV
+#define SW_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SW_SCHED_FENCE() ((void)0)
+#endif
 
 /* ---- the three non-trivial instructions, with host restatements of their ISA semantics -------------------------- */
 /* v_perm_b32: byte i of the result = BYTE_PERMUTE({s0, s1}, sel byte i): 0..3 bytes of s1, 4..7 bytes of s0,
@@ -66,14 +75,15 @@ SW_FN uint32_t sw_perm(uint32_t s0, uint32_t s1, uint32_t sel)
     return r;
 #endif
 }
-/* v_alignbyte_b32: ({s0, s1} >> (8 * s2)) & 0xffffffff; used with s2 in 0..4 only */
+/* v_alignbyte_b32: ({s0, s1} >> (8 * s2[1:0])) & 0xffffffff (gfx950 reads two bits of s2: checked on the device by
+ * tests/test_gpu_swar.py); used with s0 == s1 as a byte rotation, where 4 and 0 both mean "no rotation" */
 SW_FN uint32_t sw_alignbyte(uint32_t s0, uint32_t s1, uint32_t s2)
 {
 #if SW_DEV
     return __builtin_amdgcn_alignbyte(s0, s1, s2);
 #else
     const uint64_t in = ((uint64_t)s0 << 32) | s1;
-    return (uint32_t)(in >> (8 * (s2 & 7u)));
+    return (uint32_t)(in >> (8 * (s2 & 3u)));
 #endif
 }
 /* v_bitop3_b32: bit i of the result = bit ((a_i << 2) | (b_i << 1) | c_i) of the truth table */
@@ -98,6 +108,7 @@ SW_FN uint32_t sw_bitop3(uint32_t a, uint32_t b, uint32_t c)
 #define SW_TT_XORAND 0x28 /* (a ^ b) & c         */
 #define SW_TT_BFI_C 0xd8 /* c ? b : a            */
 #define SW_TT_ANDNOT_OR 0xf8 /* a | (b & c)      */
+#define SW_TT_XNOR_AND 0x82 /* ~(a ^ b) & c        */
 
 /* a constant that must live in a VGPR (VOP3 takes no literal, and an SGPR operand halves the issue rate) */
 SW_FN uint32_t sw_vconst(uint32_t k)
@@ -227,7 +238,7 @@ SW_FN uint32_t sw_update(uint32_t tb, uint32_t ms, const SwUpd& u, uint32_t sel_
  * Tab: tab.sb(j) = block column * 256 + shift of edge j (uniform), tab.sb_dyn(idx) the same for a per-lane edge index.
  * rowpar: byte mask, 0xff in byte k if the syndrome bit of row i + 64 k is set (only read by the OMS selective offset
  * and the 2B1C error-floor tables); lme: unsat < floor_err_count for this codeword.
- * METHOD 0 requires Factor_1 == Factor_2 here (one normalisation factor; the two-factor variant keeps the 2-row kernel). */
+ * DecodeMethod 0 (NMS) is not built here: its minima run over |t| up to 31, more levels than the 8-entry thermometer holds. */
 template <int METHOD, int DEG, class Tab>
 SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, uint32_t lane, int deg, SwRow cur, bool fresh,
                           uint32_t rowpar, bool lme)
@@ -238,6 +249,10 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     const uint32_t c78 = sw_vconst(0x78787878u), c0642 = sw_vconst(0x06040200u), cfc = sw_vconst(0xfcu);
     const uint32_t sel_sign = sw_vconst(SW_SEL_SIGN);
     const uint32_t tid4 = lane << 2;
+    /* the layer's circulants first (scalar loads share the LDS counter: in flight together with LDS reads they force full drains) */
+    uint32_t sbj[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) sbj[j] = (DEG > 0 || j < deg) ? tab.sb(j) : 0u;
 
     /* ---- the row's old messages: +-c2 on every edge (8 +- c2 as a v_perm table indexed 2 k + negative) ---- */
     const uint32_t c2o = cur.cw & 0x07070707u, c1o = (cur.cw >> 3) & 0x07070707u;
@@ -256,15 +271,16 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
         lds.wr8(a0, r); lds.wr8(a1, r >> 8); lds.wr8(a2, r >> 16); lds.wr8(a3, r >> 24);
     }
 
-    uint32_t tb[NJ], ts[NJ], ad[NJ], rq[NJ];
+    SW_SCHED_FENCE();
+    uint32_t tb[NJ], ts[NJ], ms[NJ], ad[NJ], rq[NJ], ld[NJ];
     uint32_t t1 = 0xffffffffu, t2 = 0xffffffffu, ta[5] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
     uint32_t sx = 0;
 
-    /* ---- pass 1 (CDecoder_FAID.cpp:662-861, CDecoder_OMS.cpp:363-380) ---- */
+    /* ---- pass 1 (CDecoder_FAID.cpp:662-861, CDecoder_OMS.cpp:363-380): all addresses, then all reads, then the arithmetic ---- */
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         if (DEG > 0 || j < deg) {
-            const uint32_t sb = tab.sb(j);
+            const uint32_t sb = sbj[j];
             const uint32_t x4 = tid4 + ((sb & 255u) << 2);
 #if SW_DEV
             uint32_t a;
@@ -272,10 +288,17 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
 #else
             const uint32_t a = (x4 & cfc) | (sb & ~255u);
 #endif
-            const uint32_t q = x4 >> 8;
-            ad[j] = a; rq[j] = q;
-            const uint32_t d = lds.rd32(a);
-            const uint32_t r = sw_alignbyte(d, d, q);                 /* byte k = En + 120 of row k */
+            ad[j] = a; rq[j] = x4 >> 8;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (DEG > 0 || j < deg) ld[j] = lds.rd32(ad[j]);
+    SW_SCHED_FENCE();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (DEG > 0 || j < deg) {
+            const uint32_t r = sw_alignbyte(ld[j], ld[j], rq[j]);     /* byte k = En + 120 of row k */
             const uint32_t x0 = (j & 7) ? cur.x[j >> 3] >> (j & 7) : cur.x[j >> 3];
             const uint32_t sel = sw_bitop3<SW_TT_ANDOR>(x0, c01, c0642);
             const uint32_t t = r + sw_perm(kt_hi, kt_lo, sel);       /* t + 128, VECTOR_SUB_AND_SATURATE comes in pass 2 */
@@ -283,11 +306,17 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
             /* FAID: a zero V2C takes the sign of En (CDecoder_FAID.cpp:682); En == Lold there, so it is the stored sign */
             const uint32_t s = MINSUM ? t : t - (x0 & c01);
             ts[j] = s;
-            sx ^= s;
-            /* |t| -> min(|t|, 7) -> thermometer: one's complement of the negative side plus 1, saturation through bit 7 */
-            const uint32_t mp = sw_mask7(t, sel_sign);                /* t >= 0 */
-            const uint32_t m = sw_bitop3<SW_TT_XOR3>(t, c7f, mp);
-            const uint32_t w = m + sw_bitop3<SW_TT_NANDOR>(mp, c01, c78);
+            if (j & 1) sx = sw_bitop3<SW_TT_XOR3>(sx, ts[j - 1], s); else if (j == (DEG > 0 ? DEG : deg) - 1) sx ^= s;
+            /* |t| -> min(|t|, 7) -> thermometer.  With m = 0xff where the (back-tracked) sign is "not negative":
+             *   not negative: ts ^ 0x80 = t - b,  |t| = that + b          negative: ts ^ 0x7f = -t - 1 + b,  |t| = that + 1 - b
+             * (b = 0 for the min-sum decoders); 0x78 is added on top so that |t| >= 8 reaches bit 7, which the table look-up
+             * turns into the saturated code */
+            const uint32_t m = sw_mask7(s, sel_sign);
+            ms[j] = m;
+            const uint32_t a0 = sw_bitop3<SW_TT_XOR3>(s, c7f, m);
+            const uint32_t inc = MINSUM ? sw_bitop3<SW_TT_NANDOR>(m, c01, c78)
+                                        : (sw_bitop3<SW_TT_XNOR_AND>(x0, m, c01) | c78); /* (b == (m & 1)) ? 1 : 0 */
+            const uint32_t w = a0 + inc;
             const uint32_t u = sw_perm(tt_hi, tt_lo, w & 0x87878787u);
             t2 = sw_bitop3<SW_TT_A_AND_BORC>(t2, t1, u);              /* VECTOR_MIN_2 with the old min1 */
             t1 &= u;
@@ -300,18 +329,8 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     /* ---- the row's new magnitudes ---- */
     uint32_t min1 = sw_popcount7(t1), min2 = sw_popcount7(t2);
     uint32_t c1n, c2n;
-    if (METHOD == 0) {
-        /* cste = min(((min * Factor) & 0xffff) >> 5, 7) (CLDPC.cpp:337-352); minima above 7 were clamped by the
-         * thermometer, which is harmless only while 7 * Factor >> 5 already saturates...  NMS keeps |t| up to 31:
-         * this path is used by the caller only when that holds (Factor >= 37), otherwise the 2-row kernel runs. */
-        const uint32_t g = (uint32_t)(uint16_t)(int16_t)p.f1;
-        c2n = 0; c1n = 0;
-        for (int k = 0; k < 4; ++k) {
-            uint32_t a = ((((min1 >> (8 * k)) & 0xffu) * g) & 0xffffu) >> 5, b = ((((min2 >> (8 * k)) & 0xffu) * g) & 0xffffu) >> 5;
-            c2n |= (a > 7 ? 7u : a) << (8 * k);
-            c1n |= (b > 7 ? 7u : b) << (8 * k);
-        }
-    } else if (SW_OMS(METHOD)) {
+    static_assert(METHOD != 0, "NMS keeps |t| up to 31 in its minima: it runs on the two-rows-per-lane kernel");
+    if (SW_OMS(METHOD)) {
         c2n = 0; c1n = 0;
         for (int k = 0; k < 4; ++k) {
             const bool F = ((rowpar >> (8 * k)) & 1u) && lme;
@@ -344,15 +363,21 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     /* a tie leaves the AND of the tied indices: still an edge of the row, and in a tie c1 == c2 */
 
     /* ---- the new arg-min edge: address, exact V2C, exact new En (its En in LDS is still the old value) ---- */
-    uint32_t pa[4], gb = 0, xb = 0;
+    uint32_t pa[4], sbk[4], gb = 0, xb = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sbk[k] = tab.sb_dyn((idx >> (8 * k)) & 31u);
+    SW_SCHED_FENCE();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t x4 = tid4 + ((sbk[k] & 255u) << 2);
+        pa[k] = ((x4 & 0xfcu) | (sbk[k] & ~255u)) + (((x4 >> 8) + (uint32_t)k) & 3u);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t ik = (idx >> (8 * k)) & 31u;
-        const uint32_t sb = tab.sb_dyn(ik);
-        const uint32_t x4 = tid4 + ((sb & 255u) << 2);
-        pa[k] = ((x4 & 0xfcu) | (sb & ~255u)) + (((x4 >> 8) + (uint32_t)k) & 3u);
         gb |= lds.rd8(pa[k]) << (8 * k);
-        xb |= ((cur.x[ik >> 3] >> ((ik & 7u) + 8u * (uint32_t)k)) & 1u) << (8 * k); /* old message on that edge negative */
+        const uint32_t xw = ik < 8u ? cur.x[0] : (ik < 16u ? cur.x[1] : cur.x[2]); /* selects: a dynamic index would go through scratch */
+        xb |= ((xw >> ((ik & 7u) + 8u * (uint32_t)k)) & 1u) << (8 * k); /* old message on that edge negative */
     }
     const uint32_t selA = xb | c0642;
     const uint32_t tbA = gb + sw_perm(kt_hi, kt_lo, selA);
@@ -365,24 +390,16 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     /* ---- pass 2 (CDecoder_FAID.cpp:909-929, CDecoder_OMS.cpp:452-471): every edge as if it carried c2 ---- */
     const SwUpd u2 = sw_update_consts<MINSUM>(c2n, fm);
     uint32_t ns[3] = { 0u, 0u, 0u };
+    uint32_t cbit[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cbit[e] = sw_vconst(0x01010101u << e);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         if (DEG > 0 || j < deg) {
-            const uint32_t ms = sw_mask7(ts[j], sel_sign);
-            const uint32_t en = sw_update(tb[j], ms, u2, sel_sign);
+            const uint32_t en = sw_update(tb[j], ms[j], u2, sel_sign);
             const uint32_t nq = 4u - rq[j];
             lds.wr32(ad[j], sw_alignbyte(en, en, nq));
-            /* sign bits gathered by shifting: after the 8 edges of a word the flag of edge e sits at bit e of its byte */
-            ns[j >> 3] = sw_bitop3<SW_TT_BFI_C>(ns[j >> 3] >> 1, ts[j], c80);
-        }
-    }
-    {   /* the last word holds fewer than 8 edges */
-        const int n = DEG > 0 ? DEG : deg;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            const int cnt = n - 8 * g < 0 ? 0 : (n - 8 * g > 8 ? 8 : n - 8 * g);
-            if (cnt > 0 && cnt < 8) ns[g] = (ns[g] >> (8 - cnt)) & (0x01010101u * ((1u << cnt) - 1u));
-            if (cnt == 0) ns[g] = 0;
+            ns[j >> 3] = sw_bitop3<SW_TT_ANDNOT_OR>(ns[j >> 3], ms[j], cbit[j & 7]); /* bit e of byte k: V2C on edge 8 g + e not negative */
         }
     }
     /* the arg-min edge carries c1: its exact En replaces the as-if value pass 2 wrote (same lane, LDS operations in order) */

@@ -78,6 +78,8 @@ SYMBOLS = {
     "lnsfaid_read_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "lnsfaid_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
     "lnsfaid_host_unregister": (C.c_int, [C.c_void_p]),
+    "lnsfaid_select_kernel": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lnsfaid_kernel_rows_per_lane": (C.c_int, [C.c_void_p]),
     "lnsfaid_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32]),
     "lnsfaid_stream": (C.c_void_p, [C.c_void_p]),
     "lnsfaid_strerror": (C.c_char_p, [C.c_int]),
@@ -190,6 +192,12 @@ class Decoder:
         self._check(self.lib.lnsfaid_count_errors_device(self.ctx, d_decoded_ptr, d_input_ptr, n_groups, out),
                     "lnsfaid_count_errors_device")
         return list(out)
+
+    def select_kernel(self, rows_per_lane):
+        self._check(self.lib.lnsfaid_select_kernel(self.ctx, rows_per_lane), "lnsfaid_select_kernel")
+
+    def rows_per_lane(self):
+        return self.lib.lnsfaid_kernel_rows_per_lane(self.ctx)
 
     def kernel_time(self, reset=False):
         ms = C.c_double()

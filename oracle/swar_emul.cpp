@@ -107,3 +107,18 @@ extern "C" int swar_emul_layered(const lnsfaid_code* code, const lnsfaid_cfg* cf
     }
     return LNSFAID_OK;
 }
+
+/* host restatements of the header's building blocks, for tests/test_gpu_swar.py */
+extern "C" void swar_emul_ops(int n, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out /* [8][n] */)
+{
+    for (int i = 0; i < n; ++i) {
+        out[0 * n + i] = sw_perm(a[i], b[i], c[i]);
+        out[1 * n + i] = sw_alignbyte(a[i], b[i], c[i] % 5u);
+        out[2 * n + i] = sw_bitop3<SW_TT_SEL>(a[i], b[i], c[i]);
+        out[3 * n + i] = sw_bitop3<SW_TT_NANDOR>(a[i], b[i], c[i]);
+        out[4 * n + i] = sw_mask7(a[i], SW_SEL_SIGN);
+        out[5 * n + i] = sw_bitop3<SW_TT_A_AND_BORC>(a[i], b[i], c[i]);
+        out[6 * n + i] = sw_bitop3<SW_TT_BFI_C>(a[i], b[i], c[i]);
+        out[7 * n + i] = sw_bitop3<SW_TT_XORAND>(a[i], b[i], c[i]);
+    }
+}

@@ -123,3 +123,38 @@ def test_2b1c_confidence_threshold(abi, code50, thr):
     dec.close()
     assert np.array_equal(out, ref) and np.array_equal(stats, ref_stats)
     assert stats[:, 1].max() > 0  # the bit-flipping stage (the only user of hard2) ran
+
+
+@pytest.mark.parametrize("method", [1, 2, 3, 4, 5])
+def test_both_kernels_agree(abi, code50, method):
+    """The four-rows-per-lane kernel (default for these configurations) and the two-rows-per-lane kernel on the same batch:
+    identical frames and iteration counts, and both equal to the oracle."""
+    cfg = abi.default_cfg(method, 10)
+    n = 6
+    fix = oa.ReferenceChannel(code50, 211, 13.0).groups(3.55, n)
+    ref, ref_stats = oa.Oracle(code50, cfg).decode(fix, n)
+    dec = abi.Decoder(code50, cfg, device=0, max_groups=n)
+    assert dec.rows_per_lane() == 4
+    out4, st4 = dec.decode(fix, n)
+    dec.select_kernel(2)
+    assert dec.rows_per_lane() == 2
+    out2, st2 = dec.decode(fix, n)
+    dec.select_kernel(0)
+    dec.close()
+    assert np.array_equal(out4, ref) and np.array_equal(st4, ref_stats)
+    assert np.array_equal(out2, ref) and np.array_equal(st2, ref_stats)
+
+
+def test_kernel_selection_rules(abi, code50):
+    """NMS and tables that differ between weight classes stay on the two-rows-per-lane kernel; forcing the other is refused."""
+    cfg = abi.default_cfg(0, 4)
+    dec = abi.Decoder(code50, cfg, device=0, max_groups=1)
+    assert dec.rows_per_lane() == 2
+    with pytest.raises(RuntimeError):
+        dec.select_kernel(4)
+    dec.close()
+    cfg = abi.default_cfg(2, 4)
+    cfg.v2c_map[0][1][3] = 3  # weight class 1 differs from class 0 in iteration 1
+    dec = abi.Decoder(code50, cfg, device=0, max_groups=1)
+    assert dec.rows_per_lane() == 2
+    dec.close()
