@@ -59,6 +59,7 @@ struct lnsfaid_ctx {
     LfLaneState* d_lane = nullptr;
     int32_t* d_status[2] = { nullptr, nullptr };
     uint32_t* d_remaining = nullptr;
+    int32_t* d_live = nullptr;
     unsigned long long* d_counters = nullptr;
     uint32_t* h_remaining = nullptr;          /* pinned */
     unsigned long long* h_counters = nullptr; /* pinned */
@@ -225,7 +226,7 @@ extern "C" void lnsfaid_destroy(lnsfaid_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->d_code); (void)hipFree(ctx->d_cfg); (void)hipFree(ctx->d_en); (void)hipFree(ctx->d_rows);
     (void)hipFree(ctx->d_bits); (void)hipFree(ctx->d_lane); (void)hipFree(ctx->d_status[0]); (void)hipFree(ctx->d_status[1]);
-    (void)hipFree(ctx->d_remaining); (void)hipFree(ctx->d_counters);
+    (void)hipFree(ctx->d_remaining); (void)hipFree(ctx->d_live); (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_io_in); (void)hipFree(ctx->d_io_out); (void)hipFree(ctx->d_io_stats);
     (void)hipFree(ctx->d_fe_seeds); (void)hipFree(ctx->d_fe_draws); (void)hipFree(ctx->d_fe_codeword);
     (void)hipFree(ctx->d_fe_frames); (void)hipFree(ctx->d_fe_input);
@@ -273,6 +274,7 @@ static int create_impl(lnsfaid_ctx* ctx, const lnsfaid_code* code, const lnsfaid
     HIP_TRY(hipMalloc(&ctx->d_status[0], n_cw * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&ctx->d_status[1], n_cw * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&ctx->d_remaining, sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_live, n_cw * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&ctx->d_counters, 4 * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_remaining, sizeof(uint32_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault));
@@ -351,12 +353,13 @@ extern "C" int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput,
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n_cw = n_groups * LNSFAID_GROUP;
     HIP_TRY(hipMemsetAsync(ctx->d_status[0], 0, n_cw * sizeof(int32_t), ctx->stream)); /* every codeword fresh */
+    HIP_TRY(hipMemsetAsync(ctx->d_live, 0, n_cw * sizeof(int32_t), ctx->stream));
 
     LfKernelArgs a;
     a.code = ctx->d_code; a.cfg = ctx->d_cfg;
     a.fix_input = d_fixInput; a.decoded = d_decodedBits;
     a.st_en = ctx->d_en; a.st_rows = ctx->d_rows; a.st_bits = ctx->d_bits; a.st_lane = ctx->d_lane;
-    a.remaining = ctx->d_remaining; a.stats = d_stats; a.n_cw = (int32_t)n_cw;
+    a.remaining = ctx->d_remaining; a.live = ctx->d_live; a.stats = d_stats; a.n_cw = (int32_t)n_cw;
 
     /* every launch moves each unfinished group's front forward or finishes it; the time line has
      * max_iter + max_bf + 1 points and a group needs at most two launches per point */

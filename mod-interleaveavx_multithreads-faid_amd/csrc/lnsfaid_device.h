@@ -74,6 +74,9 @@ struct LfKernelArgs {
     const int32_t* status_cur;    /* [n_cw] decision point each codeword is parked at (snapshot)          */
     int32_t* status_next;         /* [n_cw] written by this launch                                        */
     uint32_t* remaining;          /* number of codewords not finished after this launch                   */
+    int32_t* live;                /* [n_cw] highest decision point each codeword has PASSED in this decode call, published
+                                   * while the launch runs (four-rows-per-lane kernel); proof for group mates that the
+                                   * group does not stop there */
     lnsfaid_group_stats* stats;   /* [n_groups] or null                                                   */
     int32_t n_cw;
 };

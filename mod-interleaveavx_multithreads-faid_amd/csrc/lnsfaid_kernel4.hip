@@ -97,6 +97,43 @@ __device__ bool layer0_dirty4(CCode c, int lane)
     return __ballot((acc & 0x80808080u) != 0u) != 0ull;
 }
 
+/* ---- live progress of the group -----------------------------------------------------------------
+ * A codeword may pass decision point t once it is PROVEN that its group does not stop there.  The snapshot of the previous
+ * launch gives such proofs (a lane parked beyond t); this gives more of them while the launch runs: every codeword
+ * publishes the point it is about to pass (agent-scope store, monotonic), and whoever passed t first must have been dirty
+ * at t, so "some lane of my group has passed t" proves that the group goes on.  A clean codeword looks once, never waits:
+ * without a proof it parks exactly as before, so results do not depend on timing, only the number of relaunches does.
+ * MEASURED (profiles/r02_kernel4/live_progress.txt): bit-exact, one launch fewer, but not faster - the same iterations are
+ * executed either way (SQ_INSTS_VALU 9.55 G against 9.68 G per batch at 3.6 dB) and the codewords that find no proof leave a
+ * thin, long second launch (41 Gb/s against 51 Gb/s at 3.6 dB, 102 Gb/s either way at 4.2 dB).  Built only with
+ * -DLF4_LIVE_PROOF; what is kept from the experiment is the speculative output of a parking codeword (below). */
+__device__ __forceinline__ void publish_pass(int32_t* live, int cw, int t, int tid)
+{
+#ifdef LF4_LIVE_PROOF
+    if (tid == 0) __hip_atomic_store(&live[cw], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ bool group_passed(const int32_t* live, int g, int t, int tid)
+{
+#ifndef LF4_LIVE_PROOF
+    return false;
+#else
+    int v = 0;
+    if (tid < LNSFAID_GROUP) v = __hip_atomic_load(&live[g * LNSFAID_GROUP + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __ballot(v >= t) != 0ull;
+#endif
+}
+
+/* decodedBits of this codeword from the hard-decision plane (CDecoder_FAID.cpp:7091-7102, CDecoder_OMS.cpp:2966-2967) */
+__device__ __forceinline__ void write_decoded(const uint32_t* sHard, int8_t* g_out, int N, int tid)
+{
+    uint32_t* out32 = (uint32_t*)g_out;
+    for (int i = tid; i < (N >> 2); i += LF_T4) {
+        const uint32_t bits = (sHard[i >> 3] >> ((i & 7) * 4)) & 15u;
+        out32[i] = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
+    }
+}
+
 /* ---- one layered iteration (lnsfaid_swar.h does the rows) ---- */
 template <int METHOD>
 __device__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, SwRow* __restrict__ rows, int lane, int it, const uint32_t* sP,
@@ -137,9 +174,17 @@ __device__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, SwRow* __restri
         if (deg == 23) st = sw_layer_step<METHOD, 23>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
         else if (deg == 22) st = sw_layer_step<METHOD, 22>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
         else st = sw_layer_step<METHOD, 0>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
-        if (rem > 0) rows[br * LF_T4 + lane] = st; /* the last layered iteration's messages are never read again */
+        /* take the prefetched data BEFORE the store is issued: vector-memory operations retire in order, so a wait for these
+         * loads placed after the store would also wait for the store's round trip, once per layer */
         cur = fresh ? zero : nxt;
         tabv = tabn;
+        asm volatile("" : "+v"(cur.x[0]), "+v"(cur.x[1]), "+v"(cur.x[2]), "+v"(cur.cw), "+v"(cur.pa[0]), "+v"(cur.pa[1]), "+v"(tabv));
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef LF4_EXP_NO_ROWSTORE /* timing experiment only */
+        if (rem > 0) rows[br * LF_T4 + lane] = st; /* the last layered iteration's messages are never read again */
+#else
+        asm volatile("" :: "v"(st.x[0]), "v"(st.x[1]), "v"(st.x[2]), "v"(st.cw), "v"(st.pa[0]), "v"(st.pa[1]));
+#endif
     }
 }
 
@@ -198,6 +243,21 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
         return;
     }
 
+    /* all 32 lanes parked clean at the same decision point: the group stops there (the reference's break).  Every lane
+     * wrote its hard decisions when it parked, so nothing is left to do but to say so. */
+    if (my_status != 0 && all_same) {
+        if (tid == 0) {
+            a.status_next[cw] = my_status | LF_DONE;
+            if (a.stats && lane_in_group == 0) {
+                lnsfaid_group_stats st;
+                st.iterations = prog <= max_iter ? prog - 1 : max_iter;
+                st.bf_iterations = prog <= max_iter ? 0 : prog - t_bf0;
+                a.stats[g] = st;
+            }
+        }
+        return;
+    }
+
     bool in_bf = max_bf > 0 && prog >= t_bf0 && prog != 0;
     LfLaneState ls = { 0, 0, 0, 0 };
 
@@ -232,10 +292,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
         __syncthreads();
     }
 
-    /* ---- all 32 lanes parked clean at the same decision point: the group stops here ---- */
-    const bool group_stop = (my_status != 0) && all_same;
-
-    if (!group_stop) {
+    {
         for (;;) {
             if (prog >= t_end) break; /* loops exhausted (also OMS after max_iter iterations) */
             if (max_bf > 0 && prog >= t_bf0 && !in_bf) {
@@ -268,16 +325,19 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
                 if (needs_checksums || !layer0_dirty4(c, tid)) {
                     build_plane4<false>(c, sHard, 0, tid);
                     const int unsat = syndrome<LF_T4, false>(c, a.code, sP, tid, pA, pB, sRed);
-                    if (unsat == 0 && prog >= kmax) break; /* clean on the group's front: park */
+                    /* clean on the group's front: park, unless a group mate is known to have passed this point */
+                    if (unsat == 0 && prog >= kmax && !group_passed(a.live, g, prog, tid)) break;
                     if (LF4_OMS(METHOD)) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
                     else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
                     have_par = true;
                 }
+                publish_pass(a.live, cw, prog, tid);
                 main_step4<METHOD>(c, f, a.code, g_rows, tid, prog, sP, have_par && needs_checksums, lme);
                 prog++;
             } else {
                 const int unsat = syndrome<LF_T4, false>(c, a.code, sP, tid, pA, pB, sRed);
-                if (unsat == 0 && prog >= kmax) break;
+                if (unsat == 0 && prog >= kmax && !group_passed(a.live, g, prog, tid)) break;
+                publish_pass(a.live, cw, prog, tid);
                 if (METHOD == 3) bf_step_plain<LF_T4>(c, f, a.code, sHard, sHard2 + nw /* 4 count planes in the dead En */, sP, tid, sRed);
                 else bf_step<LF_T4, METHOD>(c, f, a.code, sHard, sHard0, sHard2, sP, tid, ls, sRed);
                 prog++;
@@ -285,15 +345,10 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
         }
     }
 
-    const bool finished = group_stop || prog >= t_end;
+    const bool finished = prog >= t_end;
     if (finished) {
-        /* decodedBits[l][v] = hard decision (CDecoder_FAID.cpp:7091-7102, CDecoder_OMS.cpp:2966-2967) */
         if (!in_bf) build_plane4<false>(c, sHard, 0, tid);
-        uint32_t* out32 = (uint32_t*)g_out;
-        for (int i = tid; i < (N >> 2); i += LF_T4) {
-            const uint32_t bits = (sHard[i >> 3] >> ((i & 7) * 4)) & 15u;
-            out32[i] = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
-        }
+        write_decoded(sHard, g_out, N, tid);
         if (tid == 0) {
             a.status_next[cw] = prog | LF_DONE;
             if (a.stats && lane_in_group == 0) {
@@ -304,7 +359,9 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
             }
         }
     } else {
-        /* park: state back to HBM, status = the decision point the codeword is clean at */
+        /* park clean at decision point prog: state back to HBM for the case that the group goes on, and the hard decisions
+         * (the syndrome stage has just built the plane from this En; in the bit-flipping stage the plane is the state) as the
+         * output for the case that it stops here */
         if (!in_bf) {
             const uint32_t* src = (const uint32_t*)smem;
             for (int i = tid; i < (N >> 2); i += LF_T4) g_en[i] = src[i];
@@ -312,6 +369,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
             for (int i = tid; i < nw; i += LF_T4) { g_bits[i] = sHard[i]; g_bits[nw + i] = sHard0[i]; g_bits[2 * nw + i] = sHard2[i]; }
             if (tid == 0) a.st_lane[cw] = ls;
         }
+        write_decoded(sHard, g_out, N, tid);
         if (tid == 0) { a.status_next[cw] = prog; atomicAdd(a.remaining, 1u); }
     }
 }

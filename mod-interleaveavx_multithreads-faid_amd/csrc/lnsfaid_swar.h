@@ -43,6 +43,9 @@
 #endif
 
 #define SW_MAX_DEG 24
+#ifndef SW_ILP
+#define SW_ILP 4 /* edges whose dependency chains are interleaved in the two passes */
+#endif
 
 /* Keeps the compiler's scheduler from moving instructions across this point.  With two waves per SIMD nothing hides an LDS
  * round trip, so the layer step issues all loads of a phase back to back and only then starts consuming them; left alone the
@@ -262,6 +265,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     const uint32_t tt_lo = sw_vconst(0x07030100u), tt_hi = sw_vconst(0xff3f1f0fu);
 
     /* ---- the old arg-min edge carries c1, not c2: move its En by the difference so that "every edge carries c2" holds ---- */
+#ifndef SW_EXP_NO_OLDPATCH
     if (!fresh) {
         const uint32_t a0 = cur.pa[0] & 0xffffu, a1 = cur.pa[0] >> 16, a2 = cur.pa[1] & 0xffffu, a3 = cur.pa[1] >> 16;
         const uint32_t g = lds.rd8(a0) | (lds.rd8(a1) << 8) | (lds.rd8(a2) << 16) | (lds.rd8(a3) << 24);
@@ -270,6 +274,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
         const uint32_t r = g + sw_bitop3<SW_TT_SEL>(mneg, c1o, c2o) - sw_bitop3<SW_TT_SEL>(mneg, c2o, c1o);
         lds.wr8(a0, r); lds.wr8(a1, r >> 8); lds.wr8(a2, r >> 16); lds.wr8(a3, r >> 24);
     }
+#endif
 
     SW_SCHED_FENCE();
     uint32_t tb[NJ], ts[NJ], ms[NJ], ad[NJ], rq[NJ], ld[NJ];
@@ -295,35 +300,34 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     for (int j = 0; j < NJ; ++j)
         if (DEG > 0 || j < deg) ld[j] = lds.rd32(ad[j]);
     SW_SCHED_FENCE();
+    /* The arithmetic of an edge is one long dependency chain and the hardware issues a wave's instructions in order, so the
+     * statements below are written stage by stage over groups of SW_ILP edges: consecutive instructions then belong to
+     * different edges and do not wait for each other (two waves per SIMD cannot hide that latency). */
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        if (DEG > 0 || j < deg) {
-            const uint32_t r = sw_alignbyte(ld[j], ld[j], rq[j]);     /* byte k = En + 120 of row k */
-            const uint32_t x0 = (j & 7) ? cur.x[j >> 3] >> (j & 7) : cur.x[j >> 3];
-            const uint32_t sel = sw_bitop3<SW_TT_ANDOR>(x0, c01, c0642);
-            const uint32_t t = r + sw_perm(kt_hi, kt_lo, sel);       /* t + 128, VECTOR_SUB_AND_SATURATE comes in pass 2 */
-            tb[j] = t;
-            /* FAID: a zero V2C takes the sign of En (CDecoder_FAID.cpp:682); En == Lold there, so it is the stored sign */
-            const uint32_t s = MINSUM ? t : t - (x0 & c01);
-            ts[j] = s;
-            if (j & 1) sx = sw_bitop3<SW_TT_XOR3>(sx, ts[j - 1], s); else if (j == (DEG > 0 ? DEG : deg) - 1) sx ^= s;
-            /* |t| -> min(|t|, 7) -> thermometer.  With m = 0xff where the (back-tracked) sign is "not negative":
-             *   not negative: ts ^ 0x80 = t - b,  |t| = that + b          negative: ts ^ 0x7f = -t - 1 + b,  |t| = that + 1 - b
-             * (b = 0 for the min-sum decoders); 0x78 is added on top so that |t| >= 8 reaches bit 7, which the table look-up
-             * turns into the saturated code */
-            const uint32_t m = sw_mask7(s, sel_sign);
-            ms[j] = m;
-            const uint32_t a0 = sw_bitop3<SW_TT_XOR3>(s, c7f, m);
-            const uint32_t inc = MINSUM ? sw_bitop3<SW_TT_NANDOR>(m, c01, c78)
-                                        : (sw_bitop3<SW_TT_XNOR_AND>(x0, m, c01) | c78); /* (b == (m & 1)) ? 1 : 0 */
-            const uint32_t w = a0 + inc;
-            const uint32_t u = sw_perm(tt_hi, tt_lo, w & 0x87878787u);
-            t2 = sw_bitop3<SW_TT_A_AND_BORC>(t2, t1, u);              /* VECTOR_MIN_2 with the old min1 */
-            t1 &= u;
-#pragma unroll
-            for (int b = 0; b < 5; ++b)
-                if (!((j >> b) & 1)) ta[b] &= u;
-        }
+    for (int j0 = 0; j0 < NJ; j0 += SW_ILP) {
+        uint32_t r_[SW_ILP], x_[SW_ILP], k_[SW_ILP], a_[SW_ILP], i_[SW_ILP], u_[SW_ILP];
+#define SW_EDGES(body) _Pragma("unroll") for (int g = 0; g < SW_ILP; ++g) { const int j = j0 + g; if (j < NJ && (DEG > 0 || j < deg)) { body } }
+        SW_EDGES(r_[g] = sw_alignbyte(ld[j], ld[j], rq[j]);)                                  /* byte k = En + 120 of row k */
+        SW_EDGES(x_[g] = (j & 7) ? cur.x[j >> 3] >> (j & 7) : cur.x[j >> 3];)
+        SW_EDGES(k_[g] = sw_bitop3<SW_TT_ANDOR>(x_[g], c01, c0642);)
+        SW_EDGES(k_[g] = sw_perm(kt_hi, kt_lo, k_[g]);)
+        SW_EDGES(tb[j] = r_[g] + k_[g];)                          /* t + 128, VECTOR_SUB_AND_SATURATE comes in pass 2 */
+        /* FAID: a zero V2C takes the sign of En (CDecoder_FAID.cpp:682); En == Lold there, so it is the stored sign */
+        SW_EDGES(ts[j] = MINSUM ? tb[j] : tb[j] - (x_[g] & c01);)
+        SW_EDGES(ms[j] = sw_mask7(ts[j], sel_sign);)
+        /* |t| -> min(|t|, 7) -> thermometer.  With m = 0xff where the (back-tracked) sign is "not negative":
+         *   not negative: ts ^ 0x80 = t - b,  |t| = that + b          negative: ts ^ 0x7f = -t - 1 + b,  |t| = that + 1 - b
+         * (b = 0 for the min-sum decoders); 0x78 is added on top so that |t| >= 8 reaches bit 7, which the table look-up
+         * turns into the saturated code */
+        SW_EDGES(a_[g] = sw_bitop3<SW_TT_XOR3>(ts[j], c7f, ms[j]);)
+        SW_EDGES(i_[g] = MINSUM ? sw_bitop3<SW_TT_NANDOR>(ms[j], c01, c78) : (sw_bitop3<SW_TT_XNOR_AND>(x_[g], ms[j], c01) | c78);)
+        SW_EDGES(a_[g] = (a_[g] + i_[g]) & 0x87878787u;)
+        SW_EDGES(u_[g] = sw_perm(tt_hi, tt_lo, a_[g]);)
+        SW_EDGES(
+            if (j & 1) sx = sw_bitop3<SW_TT_XOR3>(sx, ts[j - 1], ts[j]); else if (j == (DEG > 0 ? DEG : deg) - 1) sx ^= ts[j];
+            t2 = sw_bitop3<SW_TT_A_AND_BORC>(t2, t1, u_[g]);      /* VECTOR_MIN_2 with the old min1 */
+            t1 &= u_[g];
+            _Pragma("unroll") for (int b = 0; b < 5; ++b) if (!((j >> b) & 1)) ta[b] &= u_[g];)
     }
 
     /* ---- the row's new magnitudes ---- */
@@ -365,7 +369,11 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     /* ---- the new arg-min edge: address, exact V2C, exact new En (its En in LDS is still the old value) ---- */
     uint32_t pa[4], sbk[4], gb = 0, xb = 0;
 #pragma unroll
+#ifdef SW_EXP_NO_ARGMIN /* timing experiment only: results are wrong */
+    for (int k = 0; k < 4; ++k) sbk[k] = sbj[k];
+#else
     for (int k = 0; k < 4; ++k) sbk[k] = tab.sb_dyn((idx >> (8 * k)) & 31u);
+#endif
     SW_SCHED_FENCE();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -375,7 +383,11 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t ik = (idx >> (8 * k)) & 31u;
+#ifdef SW_EXP_NO_ARGMIN
+        gb |= (ld[k] & 0xffu) << (8 * k);
+#else
         gb |= lds.rd8(pa[k]) << (8 * k);
+#endif
         const uint32_t xw = ik < 8u ? cur.x[0] : (ik < 16u ? cur.x[1] : cur.x[2]); /* selects: a dynamic index would go through scratch */
         xb |= ((xw >> ((ik & 7u) + 8u * (uint32_t)k)) & 1u) << (8 * k); /* old message on that edge negative */
     }
@@ -394,17 +406,30 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
 #pragma unroll
     for (int e = 0; e < 8; ++e) cbit[e] = sw_vconst(0x01010101u << e);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        if (DEG > 0 || j < deg) {
-            const uint32_t en = sw_update(tb[j], ms[j], u2, sel_sign);
-            const uint32_t nq = 4u - rq[j];
-            lds.wr32(ad[j], sw_alignbyte(en, en, nq));
-            ns[j >> 3] = sw_bitop3<SW_TT_ANDNOT_OR>(ns[j >> 3], ms[j], cbit[j & 7]); /* bit e of byte k: V2C on edge 8 g + e not negative */
-        }
+    for (int j0 = 0; j0 < NJ; j0 += SW_ILP) { /* stage by stage over groups of edges, as in pass 1 */
+        uint32_t oc[SW_ILP], qc[SW_ILP], lc[SW_ILP], hl[SW_ILP], ll[SW_ILP], en[SW_ILP];
+        SW_EDGES(oc[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.oc[1], u2.oc[0]);)
+        SW_EDGES(qc[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.qc[1], u2.qc[0]);)
+        SW_EDGES(lc[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.lc[1], u2.lc[0]);)
+        SW_EDGES(hl[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.hl[1], u2.hl[0]);)
+        SW_EDGES(ll[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.ll[1], u2.ll[0]);)
+        SW_EDGES(oc[g] = tb[j] - oc[g];)
+        SW_EDGES(qc[g] = tb[j] + qc[g];)
+        SW_EDGES(lc[g] = tb[j] - lc[g];)
+        SW_EDGES(oc[g] = sw_mask7(oc[g], sel_sign);)   /* over      */
+        SW_EDGES(qc[g] = sw_mask7(qc[g], sel_sign);)   /* not under */
+        SW_EDGES(en[g] = sw_bitop3<SW_TT_SEL>(qc[g], lc[g], ll[g]);)
+        SW_EDGES(en[g] = sw_bitop3<SW_TT_SEL>(oc[g], hl[g], en[g]);)
+        SW_EDGES(en[g] = sw_alignbyte(en[g], en[g], 4u - rq[j]);)
+        SW_EDGES(lds.wr32(ad[j], en[g]);)
+        SW_EDGES(ns[j >> 3] = sw_bitop3<SW_TT_ANDNOT_OR>(ns[j >> 3], ms[j], cbit[j & 7]);) /* bit e of byte k: V2C on edge 8 g + e not negative */
     }
+#undef SW_EDGES
     /* the arg-min edge carries c1: its exact En replaces the as-if value pass 2 wrote (same lane, LDS operations in order) */
 #pragma unroll
+#ifndef SW_EXP_NO_ARGMIN
     for (int k = 0; k < 4; ++k) lds.wr8(pa[k], enA >> (8 * k));
+#endif
 
     /* ---- the row's new compressed messages ---- */
     SwRow out;
