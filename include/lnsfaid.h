@@ -1,6 +1,6 @@
 /*
- * lnsfaid.h — C ABI of the MI355X-native batched LDPC decoder (50G-PON QC-LDPC,
- * DecodeMethod 1 = OMS, 2 = LNS-FAID + DTBF, 5 = LNS-FAID + 2B1C).
+ * lnsfaid.h — C ABI of the MI355X-native batched LDPC decoder (50G-PON QC-LDPC, every value of the reference's
+ * DecodeMethod switch: 0 NMS, 1 OMS, 2 LNS-FAID + DTBF, 3 OMS + BF, 4 OMS + DTBF, 5 LNS-FAID + 2B1C).
  *
  * This is the drop-in boundary for the reference's decoder member functions
  *   void CLDPC::Decode_OMS()        (reference CLDPC.h:148, CDecoder_OMS.cpp:13)
@@ -149,9 +149,9 @@ int lnsfaid_set_cfg(lnsfaid_ctx* ctx, const lnsfaid_cfg* cfg);
 int lnsfaid_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, size_t n_groups,
                    int8_t* decodedBits, lnsfaid_group_stats* stats);
 
-/* Same with device-resident buffers (pointers valid on the context's GPU).
- * Asynchronous on the context's stream except for the small per-launch
- * progress read-back; returns after the batch is complete.  d_stats optional. */
+/* Same with device-resident buffers (pointers valid on the context's GPU).  Work is queued on the context's stream; the
+ * call synchronises with it once per kernel launch (it reads back how many codewords are still open: 1 launch when
+ * nothing converges, typically 3 with early stop) and returns after the batch is complete.  d_stats optional. */
 int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput, size_t n_groups,
                           int8_t* d_decodedBits, lnsfaid_group_stats* d_stats);
 
@@ -225,6 +225,23 @@ int lnsfaid_host_unregister(void* ptr);
  * lnsfaid_io_buffers) to the host: what Decode_OMSBF / Decode_OMS_DTBF return as BFiter (reference CLDPC.h:150-151,
  * histogrammed into iterCount.txt by CSimulate.cpp:148-178) when the decoded frames themselves stay on the device. */
 int lnsfaid_read_stats(lnsfaid_ctx* ctx, lnsfaid_group_stats* stats, size_t n_groups);
+
+/* ---- multi-GPU: counters summed over RCCL (reference main.cpp:174-182) ---------------------
+ * Groups of 32 codewords are independent, so a batch shards over GPUs as contiguous ranges of whole groups with no data-path
+ * traffic; the only exchange is the sum of {TestFrame, ErrorFrame, ErrorBits, LT3ErrBitFrame} the reference's main thread
+ * forms after pthread_join.  One context per GPU (one process or one host thread each):
+ *   rank 0:     lnsfaid_comm_unique_id(id), hand `id` to the other ranks by any means (file, pipe, MPI, torch store)
+ *   every rank: lnsfaid_comm_init(ctx, n_ranks, rank, id)       (collective: returns when all ranks have called it)
+ *   per round:  lnsfaid_allreduce_counters(ctx, counters)       (in place: every rank ends up with the sums;
+ *                                                                one ncclAllReduce of 4 x uint64 on the context's stream)
+ * lnsfaid_comm_attach takes an existing ncclComm_t of the caller (not destroyed by the library) instead of creating one.
+ * RCCL is looked up at run time (the copy already loaded in the process, else librccl.so.1): LNSFAID_E_NODEVICE if absent. */
+#define LNSFAID_COMM_ID_BYTES 128
+int lnsfaid_comm_unique_id(uint8_t id[LNSFAID_COMM_ID_BYTES]);
+int lnsfaid_comm_init(lnsfaid_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t id[LNSFAID_COMM_ID_BYTES]);
+int lnsfaid_comm_attach(lnsfaid_ctx* ctx, void* nccl_comm);
+int lnsfaid_comm_destroy(lnsfaid_ctx* ctx);
+int lnsfaid_allreduce_counters(lnsfaid_ctx* ctx, uint64_t counters[4]);
 
 /* Which decode kernel the context launches.  rows_per_lane 0 (default): chosen per configuration - the byte-parallel kernel
  * with four check rows per lane and one wavefront per codeword for DecodeMethods 1..5 with FAID tables that are uniform over

@@ -7,6 +7,9 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h> /* types and enums only: the library is bound at run time (lf_rccl below) */
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -68,6 +71,9 @@ struct lnsfaid_ctx {
     int8_t* d_io_out = nullptr;
     lnsfaid_group_stats* d_io_stats = nullptr;
     int rows_per_lane = 0; /* 0: pick per configuration; 2 / 4: forced (lnsfaid_select_kernel) */
+    void* comm = nullptr;      /* ncclComm_t for lnsfaid_allreduce_counters */
+    bool comm_owned = false;
+    unsigned long long* d_reduce = nullptr;
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     /* device front-end scratch: seeds, draw counters, transmitted codeword */
@@ -219,11 +225,14 @@ static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
 }
 
 /* ---- context ------------------------------------------------------------------------------------------- */
+extern "C" int lnsfaid_comm_destroy(lnsfaid_ctx* ctx);
 extern "C" void lnsfaid_destroy(lnsfaid_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)lnsfaid_comm_destroy(ctx);
+    (void)hipFree(ctx->d_reduce);
     (void)hipFree(ctx->d_code); (void)hipFree(ctx->d_cfg); (void)hipFree(ctx->d_en); (void)hipFree(ctx->d_rows);
     (void)hipFree(ctx->d_bits); (void)hipFree(ctx->d_lane); (void)hipFree(ctx->d_status[0]); (void)hipFree(ctx->d_status[1]);
     (void)hipFree(ctx->d_remaining); (void)hipFree(ctx->d_live); (void)hipFree(ctx->d_counters);
@@ -601,6 +610,112 @@ extern "C" int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, 
     std::vector<uint32_t> st(3 * n_streams); /* CChannel::Initial without CONTINUE_SEED: IX = IY = IZ = seed (CChannel.cpp:121) */
     for (size_t i = 0; i < n_streams; ++i) st[3 * i] = st[3 * i + 1] = st[3 * i + 2] = seeds[i];
     return lnsfaid_frontend_device_states(ctx, st.data(), draws_before, n_streams, mod_type, sigma, scale, codeword, d_fixInput);
+}
+
+/* ---- multi-GPU: one process (or host thread) per GPU, the four counters summed over RCCL ---------------------------
+ * The reference sums its workers' counters on the main thread after pthread_join (main.cpp:174-182); with one context per
+ * GPU the same sum is ONE all-reduce of 4 x uint64 on the context's stream.  RCCL is bound at run time - first the copy
+ * that is already in the process (a PyTorch process carries its own), then the system library - so that the decode library
+ * has no link-time dependency on it and a communicator handed in by the caller belongs to the same RCCL instance. */
+struct LfRccl {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+static LfRccl* lf_rccl()
+{
+    static LfRccl r;
+    static bool tried = false;
+    if (tried) return r.ok ? &r : nullptr;
+    tried = true;
+    void* h = RTLD_DEFAULT;
+    if (!dlsym(RTLD_DEFAULT, "ncclAllReduce")) {
+        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { snprintf(g_hip_err, sizeof(g_hip_err), "RCCL not found: %s", dlerror()); return nullptr; }
+    }
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce;
+    if (!r.ok) snprintf(g_hip_err, sizeof(g_hip_err), "RCCL symbols missing");
+    return r.ok ? &r : nullptr;
+}
+static int rccl_fail(LfRccl* r, ncclResult_t e, const char* what)
+{
+    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, r && r->GetErrorString ? r->GetErrorString(e) : "RCCL error");
+    return LNSFAID_E_HIP;
+}
+
+extern "C" int lnsfaid_comm_unique_id(uint8_t id[LNSFAID_COMM_ID_BYTES])
+{
+    if (!id) return LNSFAID_E_INVAL;
+    static_assert(LNSFAID_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    LfRccl* r = lf_rccl();
+    if (!r) return LNSFAID_E_NODEVICE;
+    ncclUniqueId u;
+    const ncclResult_t e = r->GetUniqueId(&u);
+    if (e != ncclSuccess) return rccl_fail(r, e, "ncclGetUniqueId");
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_comm_destroy(lnsfaid_ctx* ctx)
+{
+    if (!ctx) return LNSFAID_E_INVAL;
+    if (ctx->comm && ctx->comm_owned) {
+        LfRccl* r = lf_rccl();
+        if (r) { (void)hipSetDevice(ctx->device); (void)r->CommDestroy((ncclComm_t)ctx->comm); }
+    }
+    ctx->comm = nullptr; ctx->comm_owned = false;
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_comm_init(lnsfaid_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t id[LNSFAID_COMM_ID_BYTES])
+{
+    if (!ctx || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return LNSFAID_E_INVAL;
+    LfRccl* r = lf_rccl();
+    if (!r) return LNSFAID_E_NODEVICE;
+    (void)lnsfaid_comm_destroy(ctx);
+    HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t c = nullptr;
+    const ncclResult_t e = r->CommInitRank(&c, n_ranks, u, rank);
+    if (e != ncclSuccess) return rccl_fail(r, e, "ncclCommInitRank");
+    ctx->comm = (void*)c; ctx->comm_owned = true;
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_comm_attach(lnsfaid_ctx* ctx, void* nccl_comm)
+{
+    if (!ctx) return LNSFAID_E_INVAL;
+    (void)lnsfaid_comm_destroy(ctx);
+    ctx->comm = nccl_comm; ctx->comm_owned = false; /* the caller keeps ownership */
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_allreduce_counters(lnsfaid_ctx* ctx, uint64_t counters[4])
+{
+    if (!ctx || !counters) return LNSFAID_E_INVAL;
+    if (!ctx->comm) return LNSFAID_E_INVAL; /* lnsfaid_comm_init / lnsfaid_comm_attach first */
+    LfRccl* r = lf_rccl();
+    if (!r) return LNSFAID_E_NODEVICE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->d_reduce) HIP_TRY(hipMalloc(&ctx->d_reduce, 4 * sizeof(unsigned long long)));
+    for (int i = 0; i < 4; ++i) ctx->h_counters[i] = counters[i];
+    HIP_TRY(hipMemcpyAsync(ctx->d_reduce, ctx->h_counters, 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+    const ncclResult_t e = r->AllReduce(ctx->d_reduce, ctx->d_reduce, 4, ncclUint64, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
+    if (e != ncclSuccess) return rccl_fail(r, e, "ncclAllReduce");
+    HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_reduce, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; ++i) counters[i] = ctx->h_counters[i];
+    return LNSFAID_OK;
 }
 
 /* ---- measurement hooks / misc ---------------------------------------------------------------------- */

@@ -121,6 +121,7 @@ lnsfaid_ctx* CLDPC::context(int method)
 void CLDPC::decode_with(int method)
 {
     lnsfaid_ctx* ctx = context(method);
+    m_last = ctx;
     int rc;
     if (m_device_io) {
         int8_t *d_fix = nullptr, *d_out = nullptr;
@@ -151,6 +152,7 @@ void CLDPC::DeviceChannel(int decode_method, const uint32_t* states, const uint6
     int8_t* d_fix = nullptr;
     int rc = lnsfaid_io_buffers(ctx, &d_fix, nullptr, nullptr);
     if (rc) die("lnsfaid_io_buffers", rc);
+    m_last = ctx;
     rc = lnsfaid_frontend_device_states(ctx, states, draws_before, (size_t)m_groups, mod_type, sigma, scale, nullptr, d_fix);
     if (rc) die("lnsfaid_frontend_device_states", rc);
     m_device_io = true;
@@ -228,8 +230,7 @@ void CLDPC::CollectErrors(const float* bpskinput, int Z)
 
 Statistic CLDPC::CalculateErrors()
 {
-    lnsfaid_ctx* ctx = nullptr;
-    for (auto c : m_ctx) if (c) ctx = c;
+    lnsfaid_ctx* ctx = m_last; /* the decoder that produced decodedBits (device mode: whose buffers hold them) */
     if (!ctx) die("CalculateErrors before any Decode_*", LNSFAID_E_INVAL);
     uint64_t out[4] = { 0, 0, 0, 0 };
     int rc;
@@ -246,6 +247,22 @@ Statistic CLDPC::CalculateErrors()
     Statistic s;
     s.ErrorFrame = out[1]; s.ErrorBits = out[2]; s.LT3ErrBitFrame = out[3];
     return s;
+}
+
+void CLDPC::CommInit(int decode_method, int n_ranks, int rank, const uint8_t id[LNSFAID_COMM_ID_BYTES])
+{
+    m_comm_ctx = context(decode_method);
+    const int rc = lnsfaid_comm_init(m_comm_ctx, n_ranks, rank, id);
+    if (rc) die("lnsfaid_comm_init", rc);
+}
+
+void CLDPC::AllReduceCounters(unsigned long counters[4])
+{
+    if (!m_comm_ctx) die("AllReduceCounters before CommInit", LNSFAID_E_INVAL);
+    uint64_t c[4] = { counters[0], counters[1], counters[2], counters[3] };
+    const int rc = lnsfaid_allreduce_counters(m_comm_ctx, c);
+    if (rc) die("lnsfaid_allreduce_counters", rc);
+    for (int i = 0; i < 4; ++i) counters[i] = (unsigned long)c[i];
 }
 
 double CLDPC::KernelMs(bool reset)

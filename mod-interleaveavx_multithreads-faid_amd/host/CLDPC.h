@@ -76,10 +76,17 @@ public:
     const lnsfaid_group_stats* GroupStats() const { return m_stats; }
     double KernelMs(bool reset);
 
+    /* one process per GPU: bind an RCCL communicator to the decoder of `decode_method` (collective over the ranks) and sum
+     * {TestFrame, ErrorFrame, ErrorBits, LT3ErrBitFrame} over them, as reference main.cpp:174-182 does over its threads */
+    void CommInit(int decode_method, int n_ranks, int rank, const uint8_t id[LNSFAID_COMM_ID_BYTES]);
+    void AllReduceCounters(unsigned long counters[4]);
+
 private:
     void decode_with(int method);
     lnsfaid_ctx* context(int method);
     lnsfaid_ctx* m_ctx[6]; /* one context per DecodeMethod, created on first use */
+    lnsfaid_ctx* m_last = nullptr; /* the context of the last decode / device channel call: CalculateErrors counts ITS output */
+    lnsfaid_ctx* m_comm_ctx = nullptr;
     lnsfaid_code m_code;
     int32_t m_deg[NB_DEGRES], m_deg_rows[NB_DEGRES];
     lnsfaid_group_stats* m_stats;

@@ -19,6 +19,8 @@ static const int seed_table[] = { 101, 103, 107, 109, 113, 127, 131, 137, 139, 1
     821, 823, 827, 829, 839, 953, 857, 859, 863, 877, 881, 883, 887, 907, 911, 919, 929, 937, 941, 947, 953, 967, 971, 977,
     983, 991, 997, 1009, 1013, 1019 };
 
+const char* g_dump_fixinput = nullptr;
+
 int SimulationSeed(int index)
 {
     const int n = (int)(sizeof(seed_table) / sizeof(seed_table[0]));
@@ -171,6 +173,10 @@ void CSimulate::Run()
                 ldpc->float2LimitChar_4bit(fix + (size_t)m * K, dst + (size_t)m * N, scale, (size_t)K);
                 ldpc->float2LimitChar_4bit(fix + (size_t)32 * K + (size_t)m * M, dst + (size_t)m * N + K, scale, (size_t)M);
             }
+        }
+        if (g_dump_fixinput && !device_frontend) {
+            std::ofstream dump(g_dump_fixinput, std::ios::binary | std::ios::app);
+            dump.write((const char*)ldpc->fixInput, (std::streamsize)((size_t)m_streams * bits));
         }
         const auto t0 = std::chrono::steady_clock::now();
         switch (decode_method) { /* reference CSimulate.cpp:136-164 */

@@ -40,5 +40,6 @@ private:
     std::vector<uint64_t> m_draws; /* all zero: the device front-end is handed the current generator states */
 };
 
+extern const char* g_dump_fixinput; /* --dump-fixinput F: every call appends the batch's fixInput to F (tests: BPSK noise is not reproducible elsewhere) */
 int SimulationSeed(int index); /* the reference's seed table, CSimulate.cpp:11-17 */
 #endif

@@ -10,6 +10,12 @@
  * ranges over `--gpus G` GPUs; one host thread per GPU drives its CSimulate, and the per-GPU counters are
  * summed on the host after each round exactly as reference main.cpp:174-182 does.  With T equal to the
  * reference's thread count the printed counters are identical to the reference's.
+ *
+ * One process per GPU: `--ranks N --rank r --comm-file F [--device d]` runs rank r of N cooperating processes.  The T streams
+ * are cut into N contiguous ranges exactly like the G ranges above, every rank decodes its own range on its own GPU, and the
+ * four counters are summed over RCCL after each round (lnsfaid_allreduce_counters: one 32-byte all-reduce), so every rank takes
+ * the same stop decisions; rank 0 writes Result.txt.  The RCCL id travels through the file F (rank 0 writes it, the others
+ * wait for it).
  */
 #include <sys/time.h>
 
@@ -21,6 +27,7 @@
 #include <iomanip>
 #include <iostream>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "CSimulate.h"
@@ -35,7 +42,8 @@ int main(int argc, char** argv)
     /* a container usually sees every core of the host but owns a share of them: an OpenMP team as large as the machine
      * turns every parallel region into time-slicing.  16 workers unless OMP_NUM_THREADS says otherwise. */
     setenv("OMP_NUM_THREADS", "16", 0);
-    int streams = 64, gpus = 1, max_rounds = 0;
+    int streams = 64, gpus = 1, max_rounds = 0, ranks = 1, rank = 0, device = -1;
+    const char* comm_file = nullptr;
     bool device_frontend = false, force_collect = false, encode = false;
     const char* profile = "Profile.txt";
     const char* resume = nullptr;
@@ -43,14 +51,25 @@ int main(int argc, char** argv)
         if (!strcmp(argv[i], "--streams") && i + 1 < argc) streams = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--profile") && i + 1 < argc) profile = argv[++i];
+        else if (!strcmp(argv[i], "--dump-fixinput") && i + 1 < argc) g_dump_fixinput = argv[++i]; /* test hook */
+        else if (!strcmp(argv[i], "--ranks") && i + 1 < argc) ranks = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--rank") && i + 1 < argc) rank = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--comm-file") && i + 1 < argc) comm_file = argv[++i];
         else if (!strcmp(argv[i], "--max-rounds") && i + 1 < argc) max_rounds = atoi(argv[++i]); /* 0 = reference stop rule only */
         else if (!strcmp(argv[i], "--device-frontend")) device_frontend = true; /* channel + demapper + quantiser on the GPU */
         else if (!strcmp(argv[i], "--resume") && i + 1 < argc) resume = argv[++i]; /* lastSeed table of a Temp.txt (reference CONTINUE_SEED 1) */
         else if (!strcmp(argv[i], "--encode")) encode = true; /* random information bits + the encoder derived from H (reference FAKE_ENCODE 0) */
         else if (!strcmp(argv[i], "--collect")) force_collect = true; /* collectflag = 1 from the first call (reference: once FER < 1e-5) */
-        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R] [--device-frontend] [--encode] [--collect] [--resume Temp.txt]\n", argv[0]); return 2; }
+        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R] [--device-frontend] [--encode] [--collect] [--resume Temp.txt] [--ranks N --rank r --comm-file F [--device d]]\n", argv[0]); return 2; }
     }
     if (streams < 1 || gpus < 1 || gpus > streams) { fprintf(stderr, "need 1 <= gpus <= streams\n"); return 2; }
+    if (ranks < 1 || rank < 0 || rank >= ranks || (ranks > 1 && (gpus != 1 || !comm_file || ranks > streams))) {
+        fprintf(stderr, "--ranks N needs --rank r in [0, N), --comm-file F, N <= streams, and one GPU per process\n");
+        return 2;
+    }
+    if (device < 0) device = ranks > 1 ? rank : 0;
+    const bool multi = ranks > 1 || comm_file != nullptr;
 
     Parameter_Simulation p_simulation;
     if (!ReadProfile(&p_simulation, profile)) {
@@ -61,10 +80,33 @@ int main(int argc, char** argv)
     /* contiguous stream ranges per GPU; never split a group (a stream IS a sequence of whole groups) */
     vector<CSimulate> simulate(gpus);
     for (int g = 0; g < gpus; ++g) {
-        const int first = (int)((long)streams * g / gpus), last = (int)((long)streams * (g + 1) / gpus);
+        /* this process's share of the streams (all of them unless --ranks), then that share over its GPUs */
+        const int r_first = (int)((long)streams * rank / ranks), r_last = (int)((long)streams * (rank + 1) / ranks);
+        const int mine = r_last - r_first;
+        const int first = r_first + (int)((long)mine * g / gpus), last = r_first + (int)((long)mine * (g + 1) / gpus);
         simulate[g].device_frontend = device_frontend;
         simulate[g].encode = encode;
-        simulate[g].Initial(p_simulation, first, last - first, g);
+        simulate[g].Initial(p_simulation, first, last - first, multi ? device : g);
+    }
+    if (multi) { /* RCCL communicator of this run: the id travels through --comm-file */
+        uint8_t id[LNSFAID_COMM_ID_BYTES];
+        if (rank == 0) {
+            if (lnsfaid_comm_unique_id(id)) { cerr << "RCCL is not available\n"; exit(EXIT_FAILURE); }
+            const string tmp = string(comm_file) + ".tmp";
+            ofstream f(tmp, ios::binary);
+            f.write((const char*)id, sizeof(id));
+            f.close();
+            rename(tmp.c_str(), comm_file);
+        } else {
+            bool got = false;
+            for (int tries = 0; tries < 1200 && !got; ++tries) { /* up to two minutes */
+                ifstream f(comm_file, ios::binary);
+                if (f.is_open() && f.read((char*)id, sizeof(id))) got = true;
+                else this_thread::sleep_for(chrono::milliseconds(100));
+            }
+            if (!got) { cerr << "no RCCL id in " << comm_file << "\n"; exit(EXIT_FAILURE); }
+        }
+        simulate[0].ldpc->CommInit(p_simulation.decode_method, ranks, rank, id);
     }
 
     if (resume) {
@@ -79,13 +121,14 @@ int main(int argc, char** argv)
             const size_t brace = line.find('{');
             if (brace != string::npos && sscanf(line.c_str() + brace, "{%lu,%lu,%lu}", &a, &b, &c) == 3) rows.push_back({ a, b, c });
         }
+        if (ranks > 1) { cerr << "--resume is per process: run it with --ranks 1\n"; exit(EXIT_FAILURE); }
         if ((int)rows.size() < streams) { cerr << resume << " holds " << rows.size() << " generator states, need " << streams << "\n"; exit(EXIT_FAILURE); }
         int idx = 0;
         for (auto& s : simulate)
             for (auto& ch : s.channel) { ch.RS.IX = rows[idx][0]; ch.RS.IY = rows[idx][1]; ch.RS.IZ = rows[idx][2]; ++idx; }
     }
 
-    ofstream fout("Result.txt", std::ios::app);
+    ofstream fout(rank == 0 ? "Result.txt" : "/dev/null", std::ios::app); /* rank 0 reports */
     if (!fout.is_open()) { cerr << "Cannot open Result.txt\n"; exit(EXIT_FAILURE); }
     fout << endl
          << "********************************************************************************************************************************************" << endl;
@@ -98,11 +141,11 @@ int main(int argc, char** argv)
     fout << "scale=" << p_simulation.scale << endl;
     fout << "factor_1=" << p_simulation.Factor_1 << endl << "factor_2=" << p_simulation.Factor_2 << endl;
     fout << "Punctue Number: " << _PunctureBits << " Shorten Bits" << _ShortenBits << " RATE: " << simulate[0].ldpc->m_Rate << endl;
-    fout << "streams=" << streams << " gpus=" << gpus << endl;
+    fout << "streams=" << streams << " gpus=" << gpus << " ranks=" << ranks << endl;
     fout << setw(5) << "Eb_N0" << '\t' << setw(20) << "TestFrame" << '\t' << setw(15) << "ErrorFrame" << '\t' << setw(20) << "ErrorBits"
          << '\t' << setw(20) << "FER" << '\t' << setw(20) << "BER" << '\t' << setw(15) << "LT3ErrBitFrame" << '\t' << setw(15) << "Time(s)" << '\t' << endl;
     fout.close();
-    cout << setw(5) << "Eb_N0" << setw(20) << "TestFrame" << setw(15) << "ErrorFrame" << setw(20) << "ErrorBits" << setw(20) << "FER"
+    if (rank == 0) cout << setw(5) << "Eb_N0" << setw(20) << "TestFrame" << setw(15) << "ErrorFrame" << setw(20) << "ErrorBits" << setw(20) << "FER"
          << setw(20) << "BER" << setw(15) << "LT3ErrBitFrame" << setw(15) << "Time(s)" << setw(18) << "decode info Gb/s" << endl;
 
     for (float snr = p_simulation.snr_start; snr < p_simulation.snr_end; snr += p_simulation.snr_pass) {
@@ -121,13 +164,16 @@ int main(int argc, char** argv)
             vector<thread> workers; /* Start()/End() of the reference: create + join per round (CSimulate.cpp:255-278) */
             for (int g = 0; g < gpus; ++g) workers.emplace_back([&simulate, g]() { simulate[g].Run(); });
             for (auto& w : workers) w.join();
+            unsigned long add[4] = { 0, 0, 0, 0 };
             for (auto& s : simulate) { /* reference main.cpp:174-182: the reference adds the running totals again each round */
-                TestFrame += s.TestFrame; ErrorFrame += s.ErrorFrame; ErrorBits += s.ErrorBits; LT3ErrBitFrame += s.LT3ErrBitFrame;
+                add[0] += s.TestFrame; add[1] += s.ErrorFrame; add[2] += s.ErrorBits; add[3] += s.LT3ErrBitFrame;
             }
+            if (multi) simulate[0].ldpc->AllReduceCounters(add); /* the same sum over the ranks' GPUs */
+            TestFrame += add[0]; ErrorFrame += add[1]; ErrorBits += add[2]; LT3ErrBitFrame += add[3];
             BER = (double)(ErrorBits > 0 ? ErrorBits : 1) / ((double)TestFrame * (NmoinsK - _ShortenBits));
             FER = (double)(ErrorFrame > 0 ? ErrorFrame : 1) / TestFrame;
             if (FER < 1E-5 || force_collect) collectflag = 1; /* reference main.cpp:190-192: dump the error frames from here on */
-            ofstream tout("Temp.txt", std::ios::out);
+            ofstream tout(ranks > 1 ? ("Temp.txt.rank" + to_string(rank)).c_str() : "Temp.txt", std::ios::out); /* per rank: its own generator states */
             tout << setw(5) << snr << '\t' << setw(20) << TestFrame << '\t' << setw(15) << ErrorFrame << '\t' << setw(20) << ErrorBits << '\t'
                  << setw(20) << FER << '\t' << setw(20) << BER << '\t' << setw(15) << LT3ErrBitFrame << '\t' << endl;
             tout << "const unsigned long lastSeed[" << streams << "][3] = {\n"; /* resume table, reference main.cpp:200-207 */
@@ -144,9 +190,9 @@ int main(int argc, char** argv)
         unsigned long groups = 0;
         for (auto& s : simulate) { decode_s = decode_s > s.decode_seconds ? decode_s : s.decode_seconds; groups += s.decoded_groups; s.decoded_groups = 0; }
         const double gbps = decode_s > 0 ? (double)groups * 32 * NmoinsK / decode_s / 1e9 : 0;
-        cout << setw(5) << snr << setw(20) << TestFrame << setw(15) << ErrorFrame << setw(20) << ErrorBits << setw(20) << FER << setw(20) << BER
+        if (rank == 0) cout << setw(5) << snr << setw(20) << TestFrame << setw(15) << ErrorFrame << setw(20) << ErrorBits << setw(20) << FER << setw(20) << BER
              << setw(15) << LT3ErrBitFrame << setw(15) << total_time << setw(18) << gbps << endl;
-        fout.open("Result.txt", std::ios::app);
+        fout.open(rank == 0 ? "Result.txt" : "/dev/null", std::ios::app);
         fout << setw(5) << snr << '\t' << setw(20) << TestFrame << '\t' << setw(15) << ErrorFrame << '\t' << setw(20) << ErrorBits << '\t' << setw(20)
              << FER << '\t' << setw(20) << BER << '\t' << setw(15) << LT3ErrBitFrame << '\t' << setw(15) << total_time << '\t' << endl;
         fout.close();

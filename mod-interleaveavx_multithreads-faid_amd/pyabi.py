@@ -78,6 +78,11 @@ SYMBOLS = {
     "lnsfaid_read_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "lnsfaid_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
     "lnsfaid_host_unregister": (C.c_int, [C.c_void_p]),
+    "lnsfaid_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "lnsfaid_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "lnsfaid_comm_attach": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lnsfaid_comm_destroy": (C.c_int, [C.c_void_p]),
+    "lnsfaid_allreduce_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "lnsfaid_select_kernel": (C.c_int, [C.c_void_p, C.c_int32]),
     "lnsfaid_kernel_rows_per_lane": (C.c_int, [C.c_void_p]),
     "lnsfaid_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32]),
@@ -192,6 +197,14 @@ class Decoder:
         self._check(self.lib.lnsfaid_count_errors_device(self.ctx, d_decoded_ptr, d_input_ptr, n_groups, out),
                     "lnsfaid_count_errors_device")
         return list(out)
+
+    def comm_init(self, n_ranks, rank, comm_id):
+        self._check(self.lib.lnsfaid_comm_init(self.ctx, n_ranks, rank, comm_id), "lnsfaid_comm_init")
+
+    def allreduce_counters(self, counters):
+        buf = (C.c_uint64 * 4)(*[int(c) for c in counters])
+        self._check(self.lib.lnsfaid_allreduce_counters(self.ctx, buf), "lnsfaid_allreduce_counters")
+        return list(buf)
 
     def select_kernel(self, rows_per_lane):
         self._check(self.lib.lnsfaid_select_kernel(self.ctx, rows_per_lane), "lnsfaid_select_kernel")
