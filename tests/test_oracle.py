@@ -42,6 +42,26 @@ def test_oracle_reproduces_the_reference_counters_recorded_by_the_survey(abi, co
     assert (int(st[:, 0].sum()), int(st[:, 1].sum())) == (a["oracle_sum_I"], a["oracle_sum_J"])
 
 
+ITER_ANCHORS = json.load(open(os.path.join(GOLD, "anchors_iterations.json")))["rows"]
+
+
+@pytest.mark.parametrize("a", ITER_ANCHORS, ids=lambda a: "m%d_%.1fdB" % (a["method"], a["eb_n0"]))
+def test_oracle_reproduces_the_iteration_means_recorded_by_the_survey(abi, code50, a):
+    """BASELINE.md section 2 also records what the reference EXECUTED: layered (I) and bit-flipping (J) iterations per group,
+    averaged over 25 groups of the seed-101 stream, plus three more error-counter rows (all zero) over 30 calls.  The group
+    early stop, the bit-flipping break and the iteration tables all enter these numbers; the oracle (through its bit-exact AVX2
+    port, tests below) reproduces every one of them."""
+    cfg = abi.default_cfg(a["method"], 10)
+    fix = oa.ReferenceChannel(code50, 101, 13.0).groups(a["eb_n0"], 30)
+    dec, st = oa.decode_mt(code50, cfg, fix, 30, kind="avx2")
+    if "mean_I_25" in a:
+        assert round(float(st[:25, 0].mean()), 2) == a["mean_I_25"]
+        assert round(float(st[:25, 1].mean()), 2) == a["mean_J_25"]
+    if "survey_frame_errors" in a:
+        cnt = oa.Oracle(code50, cfg).count_errors(dec, None, 30)
+        assert cnt[0] == 960 and cnt[1] == a["survey_frame_errors"] and cnt[2] == a["survey_bit_errors"]
+
+
 @pytest.mark.parametrize("name", GOLDEN)
 def test_oracle_against_golden_vectors(abi, code50, name):
     z, fix, dec = load_golden(name, code50.N)

@@ -1,0 +1,40 @@
+"""CPU check of the four-rows-per-lane layer step: csrc/lnsfaid_swar.h compiled for the host (oracle/swar_emul.cpp; the ISA
+semantics of v_perm_b32 / v_alignbyte_b32 / v_bitop3_b32 are restated in that header and checked against the device by
+tests/test_gpu_swar.py) must leave exactly the oracle's a-posteriori LLRs after every layered iteration."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_abi as oa
+
+EMU = os.path.join(oa.ORACLE_DIR, "libswar_emul.so")
+
+
+def _both(abi, code50, method, eb_n0, n_iter, spec, seed=101, max_iter=10):
+    lib = oa.load()
+    lib.lnsfaid_oracle_layered_en.restype = C.c_int
+    lib.lnsfaid_oracle_layered_en.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    em = C.CDLL(EMU)
+    em.swar_emul_layered.restype = C.c_int
+    em.swar_emul_layered.argtypes = [C.POINTER(abi.Code), C.POINTER(abi.Cfg), C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    cfg = abi.default_cfg(method, max_iter)
+    fix = oa.ReferenceChannel(code50, seed, 13.0).groups(eb_n0, 1)
+    o = oa.Oracle(code50, cfg)
+    ref = np.empty(32 * code50.N, dtype=np.int8)
+    assert lib.lnsfaid_oracle_layered_en(o.h, fix.ctypes.data, n_iter, ref.ctypes.data) == 0
+    got = np.empty(32 * code50.N, dtype=np.int8)
+    assert em.swar_emul_layered(C.byref(code50.code), C.byref(cfg), fix.ctypes.data, n_iter, spec, got.ctypes.data) == 0
+    return ref, got
+
+
+@pytest.mark.parametrize("method,eb_n0,n_iter,spec", [(2, 3.4, 1, 1), (2, 3.4, 3, 1), (2, 3.0, 10, 0), (2, 4.2, 10, 1),
+                                                       (1, 3.4, 10, 1), (4, 3.6, 7, 0), (5, 3.4, 10, 1), (5, 3.6, 10, 0)])
+def test_swar_layer_step_equals_the_oracle(abi, code50, method, eb_n0, n_iter, spec):
+    """En of all 32 lanes after n_iter iterations (no early stop): saturations at +-31, zero messages, ties between the minima,
+    the back-tracked sign and the error-floor tables (DecodeMethod 5) / selective offsets (OMS loop) all pass through here."""
+    ref, got = _both(abi, code50, method, eb_n0, n_iter, spec)
+    bad = np.nonzero(ref != got)[0]
+    assert bad.size == 0, "En differs at %s: oracle %s, layer step %s" % (bad[:8].tolist(), ref[bad[:8]].tolist(), got[bad[:8]].tolist())
+    assert np.abs(ref).max() == 31  # the batch reaches the saturation limit: the merged clamp is exercised
