@@ -224,6 +224,16 @@ static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
     return LNSFAID_OK;
 }
 
+/* DecodeMethod 3 counts the votes of a variable node in four bit planes (bf_step_plain): column weight <= 15.  Checked when a
+ * context is created and again when lnsfaid_set_cfg switches an existing context to DecodeMethod 3. */
+static int check_code_for_method(const LfDevCode* code, int method)
+{
+    if (method == 3)
+        for (int cb = 0; cb < code->nbc; ++cb)
+            if (code->col_weight[cb] > 15) return LNSFAID_E_CODE;
+    return LNSFAID_OK;
+}
+
 /* ---- context ------------------------------------------------------------------------------------------- */
 extern "C" int lnsfaid_comm_destroy(lnsfaid_ctx* ctx);
 extern "C" void lnsfaid_destroy(lnsfaid_ctx* ctx)
@@ -257,9 +267,8 @@ static int create_impl(lnsfaid_ctx* ctx, const lnsfaid_code* code, const lnsfaid
     rc = build_cfg(cfg, &ctx->hcfg);
     if (rc) return rc;
     ctx->n_var = ctx->hcode.n_var; ctx->n_check = ctx->hcode.n_check; ctx->k_info = ctx->hcode.k_info;
-    if (ctx->hcfg.method == 3)
-        for (int cb = 0; cb < ctx->hcode.nbc; ++cb)
-            if (ctx->hcode.col_weight[cb] > 15) return LNSFAID_E_CODE; /* plain BF counts votes in 4 bit planes */
+    rc = check_code_for_method(&ctx->hcode, ctx->hcfg.method);
+    if (rc) return rc;
     build_wcols(&ctx->hcode, ctx->hcfg.W);
     ctx->lds_bytes = lf_lds_bytes(ctx->n_var, ctx->hcode.n_words, ctx->hcode.p_words);
     if (ctx->lds_bytes > 64 * 1024) return LNSFAID_E_CODE;
@@ -313,7 +322,9 @@ extern "C" int lnsfaid_set_cfg(lnsfaid_ctx* ctx, const lnsfaid_cfg* cfg)
 {
     if (!ctx || !cfg) return LNSFAID_E_INVAL;
     LfDevCfg n;
-    const int rc = build_cfg(cfg, &n);
+    int rc = build_cfg(cfg, &n);
+    if (rc) return rc;
+    rc = check_code_for_method(&ctx->hcode, n.method);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -606,8 +617,15 @@ extern "C" int lnsfaid_frontend_device_states(lnsfaid_ctx* ctx, const uint32_t* 
 extern "C" int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, const uint64_t* draws_before, size_t n_streams,
                                        int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput)
 {
-    if (!seeds) return LNSFAID_E_INVAL;
-    std::vector<uint32_t> st(3 * n_streams); /* CChannel::Initial without CONTINUE_SEED: IX = IY = IZ = seed (CChannel.cpp:121) */
+    if (!ctx || !seeds || !draws_before || !d_fixInput) return LNSFAID_E_INVAL;
+    if (n_streams > ctx->max_groups) return LNSFAID_E_INVAL; /* before anything is sized by it */
+    if (n_streams == 0) return LNSFAID_OK;
+    std::vector<uint32_t> st; /* CChannel::Initial without CONTINUE_SEED: IX = IY = IZ = seed (CChannel.cpp:121) */
+    try {
+        st.resize(3 * n_streams);
+    } catch (...) {
+        return LNSFAID_E_NOMEM; /* nothing is thrown across the C boundary */
+    }
     for (size_t i = 0; i < n_streams; ++i) st[3 * i] = st[3 * i + 1] = st[3 * i + 2] = seeds[i];
     return lnsfaid_frontend_device_states(ctx, st.data(), draws_before, n_streams, mod_type, sigma, scale, codeword, d_fixInput);
 }

@@ -139,7 +139,16 @@ extern "C" hipError_t lf_launch_frontend(const uint32_t* d_seeds, const unsigned
 {
     const long symbols = 32L * n_var / mod_type;
     const unsigned bx = (unsigned)((symbols + 256L * FE_RUN - 1) / (256L * FE_RUN));
-    hipLaunchKernelGGL(lnsfaid_frontend_kernel, dim3(bx, (unsigned)n_streams), dim3(256), 0, stream, d_seeds, d_draws, mod_type,
-                       sigma_ch, scale, d_codeword, d_frames, n_var, n_check, interleave, d_fix);
-    return hipGetLastError();
+    /* grid.y holds at most 65535 streams: more are launched in slices (pointers advanced per slice; the kernel indexes its
+     * stream by blockIdx.y) */
+    for (int s0 = 0; s0 < n_streams; s0 += 65535) {
+        const int ns = n_streams - s0 < 65535 ? n_streams - s0 : 65535;
+        hipLaunchKernelGGL(lnsfaid_frontend_kernel, dim3(bx, (unsigned)ns), dim3(256), 0, stream, d_seeds + 3 * (size_t)s0,
+                           d_draws + s0, mod_type, sigma_ch, scale, d_codeword,
+                           d_frames ? d_frames + (size_t)s0 * 32 * (size_t)n_var : nullptr, n_var, n_check, interleave,
+                           d_fix + (size_t)s0 * 32 * (size_t)n_var);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }

@@ -37,4 +37,5 @@ def test_swar_layer_step_equals_the_oracle(abi, code50, method, eb_n0, n_iter, s
     ref, got = _both(abi, code50, method, eb_n0, n_iter, spec)
     bad = np.nonzero(ref != got)[0]
     assert bad.size == 0, "En differs at %s: oracle %s, layer step %s" % (bad[:8].tolist(), ref[bad[:8]].tolist(), got[bad[:8]].tolist())
-    assert np.abs(ref).max() == 31  # the batch reaches the saturation limit: the merged clamp is exercised
+    if n_iter == 10 and eb_n0 >= 3.4:
+        assert np.abs(ref).max() == 31  # these batches reach the saturation limit: the merged clamp is exercised
