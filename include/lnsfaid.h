@@ -80,7 +80,7 @@ typedef struct lnsfaid_cfg {
     int32_t factor_2;          /* Profile.txt Factor_2: OMS (>= 1: smaller values leave the 3-bit alphabet, E_INVAL), NMS numerator of min2 */
     int32_t floor_err_count;   /* CDecoder_OMS.cpp:28 (100) / FAID :193 (0) / 2B1C :117 (50) */
     int32_t floor_iter_thresh; /* CDecoder_OMS.cpp:29 (4)  / FAID :194 (-1) / 2B1C :118 (6) */
-    int32_t ef_elimination;    /* EF_ELIMINATION 0 (FAID :6) or 1 (2B1C :5)          */
+    int32_t ef_elimination;    /* EF_ELIMINATION 0 (FAID :6), 1 (2B1C :5) or, DecodeMethod 2 only, 2 (FAID :673-680) */
     int32_t max_bf_iter;       /* _maxBFiter 10 (CDecoder_FAID.cpp:208); 0 for OMS   */
     int32_t bf_L0;             /* _L0 50 (FAID :168) / 100 (2B1C :88)                */
     int32_t bf_L1;             /* _L1 0                                              */
@@ -119,6 +119,14 @@ int lnsfaid_cfg_default(lnsfaid_cfg* cfg, int32_t decode_method, int32_t max_ite
 #define LNSFAID_TABLES_FAID32 1
 #define LNSFAID_TABLES_FAID2 2
 int lnsfaid_cfg_table_preset(lnsfaid_cfg* cfg, int32_t preset);
+
+/* The reference's compile-time switch EF_ELIMINATION of Decode_FAID (CDecoder_FAID.cpp:6, :192-203) for a DecodeMethod 2
+ * configuration: 0 = off (the shipped build: floor_err_count 0, floor_iter_thresh -1), 1 = error-floor tables V2C_map_it*_ef
+ * on unsatisfied rows inside the window (100, 6), 2 = the same plus the erasure of CDecoder_FAID.cpp:673-680 (20, 6): inside the
+ * window the V2C message of a variable node of column weight REGULAR_COL_WEIGHT all of whose checks were unsatisfied at the
+ * iteration's syndrome stage is set to 0, once per iteration.  Modes 1 and 2 need tables that are uniform over the weight classes
+ * and non-decreasing (lnsfaid_create / lnsfaid_set_cfg return LNSFAID_E_INVAL otherwise). */
+int lnsfaid_cfg_ef_elimination(lnsfaid_cfg* cfg, int32_t mode);
 
 /* ---- decoder context --------------------------------------------------------- */
 

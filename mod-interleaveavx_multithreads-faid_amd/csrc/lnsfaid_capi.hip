@@ -170,6 +170,15 @@ static void build_wcols(LfDevCode* code, int W)
     code->n_wcols = 0;
     for (int cb = 0; cb < code->nbc; ++cb)
         if (code->col_weight[cb] == W) code->wcol[code->n_wcols++] = cb;
+    /* first occurrence of every weight-W block column in row order (reference era_[]: CDecoder_FAID.cpp:673-680) */
+    bool seen[LF_MAX_BC] = {};
+    for (int br = 0; br < LF_MAX_BR; ++br) {
+        code->era_edges[br] = 0;
+        for (int j = 0; br < code->nbr && j < code->deg[br]; ++j) {
+            const int cb = (int)(code->circ[br][j].sb / LF_Z);
+            if (code->col_weight[cb] == W && !seen[cb]) { seen[cb] = true; code->era_edges[br] |= 1u << j; }
+        }
+    }
 }
 
 static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
@@ -198,28 +207,31 @@ static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
     if ((cfg->decode_method == 1 || cfg->decode_method == 3 || cfg->decode_method == 4)
         && ((int8_t)cfg->factor_1 < 0 || (int8_t)cfg->factor_2 < 1)) return LNSFAID_E_INVAL;
     if (cfg->decode_method == 5 && cfg->ef_elimination != 1) return LNSFAID_E_INVAL;
-    if (cfg->decode_method == 2 && cfg->ef_elimination != 0) return LNSFAID_E_INVAL;
+    if (cfg->decode_method == 2 && (cfg->ef_elimination < 0 || cfg->ef_elimination > 2)) return LNSFAID_E_INVAL;
+    if (cfg->decode_method != 2 && cfg->decode_method != 5 && cfg->ef_elimination != 0) return LNSFAID_E_INVAL;
     out->uniform_w = 1;
     for (int it = 0; it < 6; ++it)
         for (int w = 0; w < 4; ++w) {
             for (int a = 0; a < 8; ++a) {
                 const int v = cfg->v2c_map[it][w][a], ve = cfg->v2c_map_ef[it][w][a];
                 if ((cfg->decode_method == 2 || cfg->decode_method == 5) && (v < 0 || v > 7)) return LNSFAID_E_INVAL; /* 3-bit message alphabet */
-                if (cfg->decode_method == 5 && (ve < 0 || ve > 7)) return LNSFAID_E_INVAL;
+                if ((cfg->decode_method == 5 || cfg->ef_elimination >= 1) && (ve < 0 || ve > 7)) return LNSFAID_E_INVAL;
                 uint32_t* l = a < 4 ? &out->lut_lo[it][w] : &out->lut_hi[it][w];
                 uint32_t* le = a < 4 ? &out->lut_ef_lo[it][w] : &out->lut_ef_hi[it][w];
                 *l |= (uint32_t)(v & 0xff) << (8 * (a & 3));
                 *le |= (uint32_t)(ve & 0xff) << (8 * (a & 3));
                 /* a table that is not non-decreasing cannot be applied after the minimum search */
-                if (a > 0 && (v < cfg->v2c_map[it][w][a - 1] || (cfg->decode_method == 5 && ve < cfg->v2c_map_ef[it][w][a - 1])))
+                if (a > 0 && (v < cfg->v2c_map[it][w][a - 1] || ((cfg->decode_method == 5 || cfg->ef_elimination >= 1) && ve < cfg->v2c_map_ef[it][w][a - 1])))
                     out->uniform_w = 0;
             }
             if (out->lut_lo[it][w] != out->lut_lo[it][0] || out->lut_hi[it][w] != out->lut_hi[it][0]) out->uniform_w = 0;
-            if (cfg->decode_method == 5
+            if ((cfg->decode_method == 5 || cfg->ef_elimination >= 1)
                 && (out->lut_ef_lo[it][w] != out->lut_ef_lo[it][0] || out->lut_ef_hi[it][w] != out->lut_ef_hi[it][0]))
                 out->uniform_w = 0;
         }
     if (cfg->decode_method == 0) out->uniform_w = (out->factor_1 == out->factor_2) ? 1 : 0; /* NMS: one factor -> patch path */
+    /* Decode_FAID with EF_ELIMINATION 1 / 2 exists in the four-rows-per-lane kernel only, which needs uniform tables */
+    if (cfg->decode_method == 2 && cfg->ef_elimination >= 1 && !out->uniform_w) return LNSFAID_E_INVAL;
     out->bf_fast = (out->W == 3 && ((int8_t)out->alpha == 0 || (int8_t)out->alpha == 1)) ? 1 : 0;
     return LNSFAID_OK;
 }
@@ -350,6 +362,7 @@ static bool kernel4_possible(const lnsfaid_ctx* ctx)
 }
 static bool use_kernel4(const lnsfaid_ctx* ctx)
 {
+    if (ctx->hcfg.method == 2 && ctx->hcfg.ef >= 1) return true; /* not built for the other kernel (build_cfg made sure it applies) */
     if (ctx->rows_per_lane == 2) return false;
     return kernel4_possible(ctx);
 }
@@ -358,6 +371,7 @@ extern "C" int lnsfaid_select_kernel(lnsfaid_ctx* ctx, int32_t rows_per_lane)
 {
     if (!ctx || (rows_per_lane != 0 && rows_per_lane != 2 && rows_per_lane != 4)) return LNSFAID_E_INVAL;
     if (rows_per_lane == 4 && !kernel4_possible(ctx)) return LNSFAID_E_INVAL;
+    if (rows_per_lane == 2 && ctx->hcfg.method == 2 && ctx->hcfg.ef >= 1) return LNSFAID_E_INVAL;
     ctx->rows_per_lane = rows_per_lane;
     return LNSFAID_OK;
 }

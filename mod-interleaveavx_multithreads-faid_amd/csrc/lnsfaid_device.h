@@ -43,6 +43,8 @@ struct LfDevCode {
                                                * column (low / high 16 bits), .y = bit offset; unused slots: the zero word, 0     */
     int32_t col_weight[LF_MAX_BC];
     int32_t wcol[LF_MAX_BC];                  /* the n_wcols block columns of weight W                           */
+    uint32_t era_edges[LF_MAX_BR];            /* bit j: edge j of the layer is the FIRST edge, in row order, of a block column of
+                                               * weight W (EF_ELIMINATION 2 erases a variable node's V2C once per iteration)      */
     uint32_t colcirc[LF_MAX_BC][LF_MAX_COLW]; /* block row | shift << 8 for every circulant of the column         */
 };
 

@@ -134,10 +134,33 @@ __device__ __forceinline__ void write_decoded(const uint32_t* sHard, int8_t* g_o
     }
 }
 
+/* ---- EF_ELIMINATION 2: bit plane "every check of this variable node is unsatisfied" over the block columns of weight W
+ * (flip_vote[v] >= REGULAR_COL_WEIGHT, CDecoder_FAID.cpp:306-309, :675), bit-sliced like the flip decision: per (column,
+ * 64-node window) the AND of the W rotated windows of the parity plane.  Written over the hard-decision plane, which is dead
+ * between the syndrome stage and the next one. */
+__device__ void build_erasure_plane4(CCode c, const LfDevCode* gc, uint32_t* plane, const uint32_t* sP, int W, int tid)
+{
+    const int units = c->n_wcols * 4;
+    for (int u = tid; u < units; u += LF_T4) {
+        const int cb = gc->wcol[u >> 2];
+        const uint32_t win = (uint32_t)(u & 3);
+        uint32_t lo = 0xffffffffu, hi = 0xffffffffu;
+        for (int k = 0; k < W; ++k) {
+            const uint32_t cc = gc->colcirc[cb][k];
+            uint32_t a, b;
+            window64(sP + (cc & 0xffu) * 8u, (64u * win - ((cc >> 8) & 0xffu)) & 255u, a, b);
+            lo &= a; hi &= b;
+        }
+        plane[cb * 8 + 2 * (int)win] = lo;
+        plane[cb * 8 + 2 * (int)win + 1] = hi;
+    }
+    __syncthreads();
+}
+
 /* ---- one layered iteration (lnsfaid_swar.h does the rows) ---- */
-template <int METHOD>
+template <int METHOD, bool ERA>
 __device__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, SwRow* __restrict__ rows, int lane, int it, const uint32_t* sP,
-                           bool have_par, bool lme)
+                           bool have_par, bool lme, uint32_t era_plane)
 {
     const bool fresh = (it == 1); /* no iteration has run yet: every Lmn is still 0, nothing in HBM */
     const int rem = f->max_iter - it;
@@ -147,6 +170,7 @@ __device__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, SwRow* __restri
     p.ef_lo = f->lut_ef_lo[itx][0]; p.ef_hi = f->lut_ef_hi[itx][0];
     p.f1 = f->factor_1; p.f2 = f->factor_2;
     p.window = rem <= f->floor_iter_thresh;
+    p.ef_tables = f->ef >= 1;
     const int nbr = c->nbr;
     const SwLds lds = SwLds();
     const SwRow zero = { { 0u, 0u, 0u }, 0u, { 0u, 0u } }; /* Lmn = 0 before the first iteration (CDecoder_FAID.cpp:211-214) */
@@ -171,7 +195,9 @@ __device__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, SwRow* __restri
         DevTab4 tab;
         tab.c = c; tab.br = br; tab.sbv = tabv;
         SwRow st;
-        if (deg == 23) st = sw_layer_step<METHOD, 23>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
+        const uint32_t era_edges = ERA ? c->era_edges[br] : 0u;
+        if (ERA) st = sw_layer_step<METHOD, 0, ERA>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme, era_edges, era_plane); /* rare: one instance */
+        else if (deg == 23) st = sw_layer_step<METHOD, 23>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
         else if (deg == 22) st = sw_layer_step<METHOD, 22>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
         else st = sw_layer_step<METHOD, 0>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
         /* take the prefetched data BEFORE the store is issued: vector-memory operations retire in order, so a wait for these
@@ -321,7 +347,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
                 /* l_checksum_ and the unsatisfied count are consumed only inside the error-floor window
                  * (nombre_iterations <= floor_iter_thresh: OMS selective offset CDecoder_OMS.cpp:388, 2B1C tables
                  * CDecoder_FAID.cpp:714) and never by DecodeMethod 2; elsewhere only unsat != 0 matters */
-                const bool needs_checksums = (METHOD != 2) && (max_iter - prog <= f->floor_iter_thresh);
+                const bool needs_checksums = max_iter - prog <= f->floor_iter_thresh; /* never for the shipped DecodeMethod 2: -1 */
                 if (needs_checksums || !layer0_dirty4(c, tid)) {
                     build_plane4<false>(c, sHard, 0, tid);
                     const int unsat = syndrome<LF_T4, false>(c, a.code, sP, tid, pA, pB, sRed);
@@ -332,7 +358,13 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
                     have_par = true;
                 }
                 publish_pass(a.live, cw, prog, tid);
-                main_step4<METHOD>(c, f, a.code, g_rows, tid, prog, sP, have_par && needs_checksums, lme);
+                if (METHOD == 2 && f->ef == 2 && needs_checksums && have_par && lme) {
+                    /* EF_ELIMINATION 2 inside the window, few unsatisfied checks: this iteration erases (CDecoder_FAID.cpp:673-680) */
+                    build_erasure_plane4(c, a.code, sHard, sP, f->W, tid);
+                    main_step4<METHOD, METHOD == 2>(c, f, a.code, g_rows, tid, prog, sP, true, lme, lf_lds_off_hard(N));
+                } else {
+                    main_step4<METHOD, false>(c, f, a.code, g_rows, tid, prog, sP, have_par && needs_checksums, lme, 0u);
+                }
                 prog++;
             } else {
                 const int unsat = syndrome<LF_T4, false>(c, a.code, sP, tid, pA, pB, sRed);

@@ -156,6 +156,7 @@ struct SwParams {
     uint32_t ef_lo, ef_hi;         /* error-floor table (DecodeMethod 5)                                        */
     int32_t f1, f2;                /* Factor_1 / Factor_2 (OMS offsets, NMS numerators)                          */
     int32_t window;                /* nombre_iterations <= floor_iter_thresh                                     */
+    int32_t ef_tables;             /* EF_ELIMINATION >= 1 (always so for DecodeMethod 5; 0, 1 or 2 for DecodeMethod 2)  */
 };
 
 /* LDS seen by the layer step: byte offsets inside the codeword's En image (block column cb at cb * 256). */
@@ -237,15 +238,29 @@ SW_FN uint32_t sw_update(uint32_t tb, uint32_t ms, const SwUpd& u, uint32_t sel_
     return sw_bitop3<SW_TT_SEL>(mo, hl, sw_bitop3<SW_TT_SEL>(mq, tb - lc, ll));
 }
 
+/* ERA helpers.  Plane bit of the variable node at LDS byte address a (interleaved image: block column in the high bits,
+ * dword = node mod 64, byte = node div 64); returns 0 / 1. */
+SW_FN uint32_t sw_plane_bit(const SwLds& lds, uint32_t era_plane, uint32_t a)
+{
+    const uint32_t v = (a & ~255u) | ((a >> 2) & 63u) | ((a & 3u) << 6); /* node index */
+    return (lds.rd32(era_plane + ((v >> 5) << 2)) >> (v & 31u)) & 1u;
+}
+
 /* ---- one layer -----------------------------------------------------------------------------------------------------
  * Tab: tab.sb(j) = block column * 256 + shift of edge j (uniform), tab.sb_dyn(idx) the same for a per-lane edge index.
  * rowpar: byte mask, 0xff in byte k if the syndrome bit of row i + 64 k is set (only read by the OMS selective offset
  * and the 2B1C error-floor tables); lme: unsat < floor_err_count for this codeword.
  * DecodeMethod 0 (NMS) is not built here: its minima run over |t| up to 31, more levels than the 8-entry thermometer holds. */
-template <int METHOD, int DEG, class Tab>
+template <int METHOD, int DEG, bool ERA = false, class Tab>
 SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, uint32_t lane, int deg, SwRow cur, bool fresh,
-                          uint32_t rowpar, bool lme)
+                          uint32_t rowpar, bool lme, uint32_t era_edges = 0u, uint32_t era_plane = 0u)
 {
+    /* ERA (EF_ELIMINATION 2, CDecoder_FAID.cpp:673-680; the caller instantiates it only inside the error-floor window of a
+     * codeword with few unsatisfied checks): era_edges bit j = edge j is the first edge, in row order, of a block column of
+     * weight REGULAR_COL_WEIGHT; era_plane = LDS byte offset of a bit plane over the variable nodes, bit set = every check of
+     * the node was unsatisfied at this iteration's syndrome stage.  On those edges the V2C becomes 0 for such nodes and its
+     * sign is the sign of En itself (the back-track of :682 with vContr == 0). */
+    static_assert(!ERA || METHOD == 2, "the erasure exists in Decode_FAID only");
     constexpr int NJ = DEG > 0 ? DEG : SW_MAX_DEG;
     constexpr bool MINSUM = SW_MINSUM(METHOD);
     const uint32_t c01 = sw_vconst(0x01010101u), c80 = sw_vconst(0x80808080u), c7f = sw_vconst(0x7f7f7f7fu);
@@ -265,13 +280,15 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     const uint32_t tt_lo = sw_vconst(0x07030100u), tt_hi = sw_vconst(0xff3f1f0fu);
 
     /* ---- the old arg-min edge carries c1, not c2: move its En by the difference so that "every edge carries c2" holds ---- */
+    uint32_t padd = 0, psub = 0; /* what the patch below adds to / takes from the old arg-min nodes' LDS bytes */
 #ifndef SW_EXP_NO_OLDPATCH
     if (!fresh) {
         const uint32_t a0 = cur.pa[0] & 0xffffu, a1 = cur.pa[0] >> 16, a2 = cur.pa[1] & 0xffffu, a3 = cur.pa[1] >> 16;
         const uint32_t g = lds.rd8(a0) | (lds.rd8(a1) << 8) | (lds.rd8(a2) << 16) | (lds.rd8(a3) << 24);
         const uint32_t mneg = sw_mask7(cur.cw << 1, sel_sign); /* bit 6: the arg-min message is negative */
         /* En - L(c1) = (En - sigma (c1 - c2)) - sigma c2 */
-        const uint32_t r = g + sw_bitop3<SW_TT_SEL>(mneg, c1o, c2o) - sw_bitop3<SW_TT_SEL>(mneg, c2o, c1o);
+        padd = sw_bitop3<SW_TT_SEL>(mneg, c1o, c2o); psub = sw_bitop3<SW_TT_SEL>(mneg, c2o, c1o);
+        const uint32_t r = g + padd - psub;
         lds.wr8(a0, r); lds.wr8(a1, r >> 8); lds.wr8(a2, r >> 16); lds.wr8(a3, r >> 24);
     }
 #endif
@@ -306,14 +323,31 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
 #pragma unroll
     for (int j0 = 0; j0 < NJ; j0 += SW_ILP) {
         uint32_t r_[SW_ILP], x_[SW_ILP], k_[SW_ILP], a_[SW_ILP], i_[SW_ILP], u_[SW_ILP];
-#define SW_EDGES(body) _Pragma("unroll") for (int g = 0; g < SW_ILP; ++g) { const int j = j0 + g; if (j < NJ && (DEG > 0 || j < deg)) { body } }
+#define SW_EDGES(...) _Pragma("unroll") for (int g = 0; g < SW_ILP; ++g) { const int j = j0 + g; if (j < NJ && (DEG > 0 || j < deg)) { __VA_ARGS__ } }
         SW_EDGES(r_[g] = sw_alignbyte(ld[j], ld[j], rq[j]);)                                  /* byte k = En + 120 of row k */
         SW_EDGES(x_[g] = (j & 7) ? cur.x[j >> 3] >> (j & 7) : cur.x[j >> 3];)
         SW_EDGES(k_[g] = sw_bitop3<SW_TT_ANDOR>(x_[g], c01, c0642);)
         SW_EDGES(k_[g] = sw_perm(kt_hi, kt_lo, k_[g]);)
         SW_EDGES(tb[j] = r_[g] + k_[g];)                          /* t + 128, VECTOR_SUB_AND_SATURATE comes in pass 2 */
         /* FAID: a zero V2C takes the sign of En (CDecoder_FAID.cpp:682); En == Lold there, so it is the stored sign */
-        SW_EDGES(ts[j] = MINSUM ? tb[j] : tb[j] - (x_[g] & c01);)
+        SW_EDGES(x_[g] &= c01;)                                   /* b: the old message on this edge is negative */
+        if (ERA) {
+            SW_EDGES(
+                if ((era_edges >> j) & 1u) {
+                    uint32_t em = 0, match = 0;
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {
+                        const uint32_t a = ad[j] + ((rq[j] + (uint32_t)k) & 3u); /* LDS byte of row k's node on this edge */
+                        em |= sw_plane_bit(lds, era_plane, a) ? (0xffu << (8 * k)) : 0u;
+                        const uint32_t pold = (k & 1) ? cur.pa[k >> 1] >> 16 : cur.pa[k >> 1] & 0xffffu;
+                        match |= (!fresh && a == pold) ? (0xffu << (8 * k)) : 0u;    /* that byte carries the patch */
+                    }
+                    const uint32_t en_true = r_[g] - (padd & match) + (psub & match);
+                    const uint32_t neg01 = ~((en_true + 0x08080808u) >> 7) & c01;      /* En < 0 */
+                    tb[j] = sw_bitop3<SW_TT_SEL>(em, c80, tb[j]);                      /* vContr = 0 */
+                    x_[g] = sw_bitop3<SW_TT_SEL>(em, neg01, x_[g]);                    /* its sign: the sign of En */
+                })
+        }
+        SW_EDGES(ts[j] = MINSUM ? tb[j] : tb[j] - x_[g];)
         SW_EDGES(ms[j] = sw_mask7(ts[j], sel_sign);)
         /* |t| -> min(|t|, 7) -> thermometer.  With m = 0xff where the (back-tracked) sign is "not negative":
          *   not negative: ts ^ 0x80 = t - b,  |t| = that + b          negative: ts ^ 0x7f = -t - 1 + b,  |t| = that + 1 - b
@@ -347,7 +381,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
         /* uniform non-decreasing table applied after the search; offset 0 (CDecoder_FAID.cpp:864-866) */
         c2n = sw_perm(p.lut_hi, p.lut_lo, min1);
         c1n = sw_perm(p.lut_hi, p.lut_lo, min2);
-        if (METHOD == 5 && p.window && lme) { /* mask_eef per row (CDecoder_FAID.cpp:713-720) */
+        if ((METHOD == 5 || p.ef_tables) && p.window && lme) { /* mask_eef per row (CDecoder_FAID.cpp:713-720) */
             c2n = sw_bitop3<SW_TT_SEL>(rowpar, sw_perm(p.ef_hi, p.ef_lo, min1), c2n);
             c1n = sw_bitop3<SW_TT_SEL>(rowpar, sw_perm(p.ef_hi, p.ef_lo, min2), c1n);
         }
@@ -392,7 +426,20 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
         xb |= ((xw >> ((ik & 7u) + 8u * (uint32_t)k)) & 1u) << (8 * k); /* old message on that edge negative */
     }
     const uint32_t selA = xb | c0642;
-    const uint32_t tbA = gb + sw_perm(kt_hi, kt_lo, selA);
+    uint32_t tbA = gb + sw_perm(kt_hi, kt_lo, selA);
+    if (ERA) { /* the arg-min edge of a row may be an erased one (a V2C of 0 usually IS the minimum) */
+        uint32_t em = 0, match = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ik = (idx >> (8 * k)) & 31u;
+            if ((era_edges >> ik) & 1u) em |= sw_plane_bit(lds, era_plane, pa[k]) ? (0xffu << (8 * k)) : 0u;
+            const uint32_t pold = (k & 1) ? cur.pa[k >> 1] >> 16 : cur.pa[k >> 1] & 0xffffu;
+            match |= (!fresh && pa[k] == pold) ? (0xffu << (8 * k)) : 0u;
+        }
+        const uint32_t en_true = gb - (padd & match) + (psub & match);
+        tbA = sw_bitop3<SW_TT_SEL>(em, c80, tbA);
+        xb = sw_bitop3<SW_TT_SEL>(em, ~((en_true + 0x08080808u) >> 7) & c01, xb);
+    }
     const uint32_t tsA = MINSUM ? tbA : tbA - xb;
     const uint32_t msA = sw_mask7(tsA, sel_sign);
     const SwUpd u1 = sw_update_consts<MINSUM>(c1n, fm);

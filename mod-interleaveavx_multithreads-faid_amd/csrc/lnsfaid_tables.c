@@ -169,3 +169,13 @@ int lnsfaid_cfg_default(lnsfaid_cfg* cfg, int32_t decode_method, int32_t max_ite
     }
     return LNSFAID_OK;
 }
+
+/* EF_ELIMINATION of CDecoder_FAID.cpp (:6, :192-203): 0 off (the shipped build), 1 error-floor tables, 2 tables + erasure. */
+int lnsfaid_cfg_ef_elimination(lnsfaid_cfg* cfg, int32_t mode)
+{
+    if (!cfg || cfg->decode_method != 2 || mode < 0 || mode > 2) return LNSFAID_E_INVAL;
+    cfg->ef_elimination = mode;
+    cfg->floor_err_count = mode == 0 ? 0 : (mode == 1 ? 100 : 20);
+    cfg->floor_iter_thresh = mode == 0 ? -1 : 6;
+    return LNSFAID_OK;
+}

@@ -59,6 +59,7 @@ SYMBOLS = {
     "lnsfaid_code_50gpon": (C.c_int, [C.POINTER(Code), C.POINTER(C.c_uint16), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lnsfaid_cfg_default": (C.c_int, [C.POINTER(Cfg), C.c_int32, C.c_int32]),
     "lnsfaid_cfg_table_preset": (C.c_int, [C.POINTER(Cfg), C.c_int32]),
+    "lnsfaid_cfg_ef_elimination": (C.c_int, [C.POINTER(Cfg), C.c_int32]),
     "lnsfaid_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Code), C.POINTER(Cfg), C.c_int32, C.c_size_t]),
     "lnsfaid_destroy": (None, [C.c_void_p]),
     "lnsfaid_set_cfg": (C.c_int, [C.c_void_p, C.POINTER(Cfg)]),

@@ -175,11 +175,15 @@ static void decode_group(lnsfaid_cpu* o, const int8_t* fix, int8_t* out, lnsfaid
         /* syndrome stage */
         V esum = zero;
         const uint16_t* p = o->pos;
+        const uint16_t* pv = o->pos;
+        const int erase = (c->ef_elimination == 2); /* EF_ELIMINATION 2: votes per VN from the syndrome stage, era_ flags */
+        if (erase) for (int i = 0; i < N; ++i) { o->vote[i] = zero; o->flip[i] = zero; }
         for (int r = 0; r < M; ++r) {
             V par = zero;
             for (int j = 0; j < o->row_deg[r]; ++j) par = _mm256_xor_si256(par, gt(o->En[*p++], zero));
             o->chk[r] = par;
             esum = oms ? _mm256_adds_epu8(esum, _mm256_and_si256(par, one)) : _mm256_adds_epi8(esum, _mm256_and_si256(par, one));
+            if (erase) for (int j = 0; j < o->row_deg[r]; ++j, ++pv) o->vote[*pv] = _mm256_adds_epu8(o->vote[*pv], _mm256_and_si256(par, one));
         }
         if (_mm256_testz_si256(esum, esum)) break;
         V lme;
@@ -211,6 +215,13 @@ static void decode_group(lnsfaid_cpu* o, const int8_t* fix, int8_t* out, lnsfaid
                     m = _mm256_min_epi8(_mm256_abs_epi8(t), v7);
                 } else {
                     t = _mm256_min_epi8(t, vmax);
+                    if (erase && window && o->vn_weight[col] == c->regular_col_weight) { /* CDecoder_FAID.cpp:673-680 */
+                        const V wv = set1((char)c->regular_col_weight);
+                        const V ge = _mm256_or_si256(gt(o->vote[col], wv), eq(o->vote[col], wv));
+                        const V mask = _mm256_andnot_si256(o->flip[col], _mm256_and_si256(ge, lme));
+                        t = _mm256_andnot_si256(mask, t);
+                        o->flip[col] = _mm256_or_si256(o->flip[col], mask);
+                    }
                     s = _mm256_and_si256(sel(eq(t, zero), en, t), sbit); /* sign back-track */
                     const V a = _mm256_min_epi8(_mm256_abs_epi8(t), v7);
                     const int w = wclass(o->vn_weight[col]);

@@ -99,6 +99,7 @@ struct lnsfaid_oracle {
     m32* checksum;      /* l_checksum_[_NoCheck]                               */
     v32* flip_vote;     /* [n_var]                                             */
     m32 *hard_llr, *hard2_llr, *hard_ch, *flip_record; /* [n_var] each        */
+    m32* era;           /* era_[_NoVar]: V2C of this VN already erased in this iteration (EF_ELIMINATION 2) */
 };
 
 int lnsfaid_oracle_create(lnsfaid_oracle** out, const lnsfaid_code* code, const lnsfaid_cfg* cfg)
@@ -121,8 +122,9 @@ int lnsfaid_oracle_create(lnsfaid_oracle** out, const lnsfaid_code* code, const 
     o->hard2_llr = (m32*)malloc(N * sizeof(m32));
     o->hard_ch = (m32*)malloc(N * sizeof(m32));
     o->flip_record = (m32*)malloc(N * sizeof(m32));
+    o->era = (m32*)calloc(N, sizeof(m32));
     if (!o->pos_vn || !o->row_deg || !o->vn_weight || !o->var_nodes || !o->var_msgs || !o->checksum || !o->flip_vote
-        || !o->hard_llr || !o->hard2_llr || !o->hard_ch || !o->flip_record) {
+        || !o->hard_llr || !o->hard2_llr || !o->hard_ch || !o->flip_record || !o->era) {
         lnsfaid_oracle_destroy(o);
         return LNSFAID_E_NOMEM;
     }
@@ -150,7 +152,7 @@ void lnsfaid_oracle_destroy(lnsfaid_oracle* o)
     if (!o) return;
     free(o->pos_vn); free(o->row_deg); free(o->vn_weight); free(o->var_nodes); free(o->var_msgs);
     free(o->checksum); free(o->flip_vote); free(o->hard_llr); free(o->hard2_llr); free(o->hard_ch);
-    free(o->flip_record);
+    free(o->flip_record); free(o->era);
     free(o);
 }
 
@@ -176,11 +178,17 @@ static v32 syndrome_stage(lnsfaid_oracle* o, int unsigned_sum)
     const v32 zero = v_set1(0), ones = v_set1(1);
     v32 error_sum = zero;
     const uint16_t* pCN = o->pos_vn;
+    const uint16_t* pCN2 = o->pos_vn;
+    /* flip_vote: unsatisfied checks per VN (CDecoder_FAID.cpp:287-290, :306-309); only EF_ELIMINATION 2 reads it */
+    const int votes = (o->cfg.ef_elimination == 2);
+    if (votes) for (int i = 0; i < o->code.n_var; ++i) o->flip_vote[i] = zero;
     for (int r = 0; r < o->code.n_check; ++r) {
         m32 mask_sum = 0;
         for (int j = 0; j < o->row_deg[r]; ++j) mask_sum ^= m_gt(o->var_nodes[*pCN++], zero);
         o->checksum[r] = mask_sum;
         error_sum = unsigned_sum ? v_addu_mask(mask_sum, error_sum, ones) : v_adds_mask(mask_sum, error_sum, ones);
+        for (int j = 0; j < o->row_deg[r]; ++j, ++pCN2)
+            if (votes) o->flip_vote[*pCN2] = v_addu_mask(mask_sum, o->flip_vote[*pCN2], ones);
     }
     return error_sum;
 }
@@ -225,6 +233,9 @@ static void layered_iteration(lnsfaid_oracle* o, int nombre_iterations /* remain
     const int it_idx = (it >= 1 && it <= 5) ? it - 1 : 5;  /* switch at CDecoder_FAID.cpp:760-779 */
     const int in_floor_window = (nombre_iterations <= c->floor_iter_thresh);
 
+    /* EF_ELIMINATION 2: at the beginning of each iteration the erase flags are cleared (CDecoder_FAID.cpp:623-628) */
+    if (c->ef_elimination == 2) memset(o->era, 0, (size_t)o->code.n_var * sizeof(m32));
+
     size_t e = 0;
     for (int r = 0; r < o->code.n_check; ++r) {
         const int deg = o->row_deg[r];
@@ -248,6 +259,13 @@ static void layered_iteration(lnsfaid_oracle* o, int nombre_iterations /* remain
                 min1 = v_min(vAbs, min1);
             } else {
                 vContr = v_min(vContr, max_var); /* CDecoder_FAID.cpp:672 */
+                /* EF_ELIMINATION 2 (CDecoder_FAID.cpp:673-680): inside the error-floor window the V2C of a weight-W variable
+                 * node all of whose checks are unsatisfied is erased, once per iteration (the first of its edges in row order) */
+                if (c->ef_elimination == 2 && o->vn_weight[col] == c->regular_col_weight && in_floor_window) {
+                    const m32 mask = m_ge(o->flip_vote[col], v_set1(c->regular_col_weight)) & l_m_error_sum & ~o->era[col];
+                    vContr = v_subs_mask(mask, vContr, vContr);
+                    o->era[col] |= mask;
+                }
                 /* FAID2_SIGN_BACKTRACK (CDecoder_FAID.cpp:682): a zero V2C takes the sign of En */
                 v32 cSign = v_and(v_adds_mask(m_eq(vContr, zero), vContr, vNoeud), msign8);
                 _sign[j] = cSign;

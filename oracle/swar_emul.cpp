@@ -22,8 +22,11 @@ struct HostTab {
 
 template <int METHOD>
 SwRow step(int deg, bool spec, const SwLds& lds, const HostTab& tab, const SwParams& p, uint32_t lane, SwRow cur, bool fresh,
-           uint32_t rowpar, bool lme)
+           uint32_t rowpar, bool lme, bool erase = false, uint32_t era_edges = 0, uint32_t era_plane = 0)
 {
+    if (erase) {
+        if constexpr (METHOD == 2) return sw_layer_step<METHOD, 0, true>(lds, tab, p, lane, deg, cur, fresh, rowpar, lme, era_edges, era_plane);
+    }
     if (spec && deg == 23) return sw_layer_step<METHOD, 23>(lds, tab, p, lane, deg, cur, fresh, rowpar, lme);
     if (spec && deg == 22) return sw_layer_step<METHOD, 22>(lds, tab, p, lane, deg, cur, fresh, rowpar, lme);
     return sw_layer_step<METHOD, 0>(lds, tab, p, lane, deg, cur, fresh, rowpar, lme);
@@ -54,7 +57,8 @@ extern "C" int swar_emul_layered(const lnsfaid_code* code, const lnsfaid_cfg* cf
     const int method = cfg->decode_method;
     const bool oms = SW_OMS(method);
     for (int l = 0; l < 32; ++l) {
-        std::vector<uint8_t> img((size_t)N + 4, 0);
+        const uint32_t plane_off = ((uint32_t)N + 15u) & ~15u; /* where the kernel keeps its hard / erasure plane */
+        std::vector<uint8_t> img((size_t)plane_off + (size_t)N / 8 + 8, 0);
         for (int v = 0; v < N; ++v) {
             int llr = v < K ? fixInput[(size_t)l * K + v] : fixInput[(size_t)32 * K + (size_t)l * M + (v - K)];
             if (v >= N - code->puncture_tail) llr = 0;
@@ -89,6 +93,25 @@ extern "C" int swar_emul_layered(const lnsfaid_code* code, const lnsfaid_cfg* cf
             }
             p.f1 = (int8_t)cfg->factor_1; p.f2 = (int8_t)cfg->factor_2;
             p.window = rem <= cfg->floor_iter_thresh;
+            p.ef_tables = cfg->ef_elimination >= 1;
+            /* EF_ELIMINATION 2: erase in this iteration?  plane bit v = all checks of v unsatisfied (weight-W columns) */
+            const int W = cfg->regular_col_weight;
+            const bool erase = method == 2 && cfg->ef_elimination == 2 && p.window && lme;
+            std::vector<uint32_t> era_edges(nbr, 0u);
+            if (erase) {
+                std::vector<int> votes(N, 0), weight(N, 0);
+                size_t e = 0;
+                for (int r = 0; r < M; ++r) { const int d = deg[r / Z]; for (int j = 0; j < d; ++j) { votes[code->pos_vn[e + j]] += par[r]; weight[code->pos_vn[e + j]]++; } e += d; }
+                memset(img.data() + plane_off, 0, (size_t)N / 8);
+                for (int v = 0; v < N; ++v)
+                    if (weight[v] == W && votes[v] >= W) img[plane_off + (size_t)(v >> 3)] |= (uint8_t)(1u << (v & 7));
+                std::vector<char> seen(N / Z, 0);
+                for (int br = 0; br < nbr; ++br)
+                    for (int j = 0; j < deg[br]; ++j) {
+                        const int cb = (int)(sb[(size_t)br * SW_MAX_DEG + j] / (uint32_t)Z);
+                        if (weight[(size_t)cb * Z] == W && !seen[cb]) { seen[cb] = 1; era_edges[br] |= 1u << j; }
+                    }
+            }
             for (int br = 0; br < nbr; ++br) {
                 HostTab tab; tab.row = &sb[(size_t)br * SW_MAX_DEG];
                 for (uint32_t lane = 0; lane < 64; ++lane) {
@@ -96,7 +119,7 @@ extern "C" int swar_emul_layered(const lnsfaid_code* code, const lnsfaid_cfg* cf
                     for (int k = 0; k < 4; ++k) if (par[(size_t)br * Z + lane + 64 * k]) rowpar |= 0xffu << (8 * k);
                     SwRow& cur = rows[(size_t)br * 64 + lane];
                     const bool fresh = (it == 1);
-                    if (method == 2) cur = step<2>(deg[br], specialised != 0, lds, tab, p, lane, cur, fresh, rowpar, lme);
+                    if (method == 2) cur = step<2>(deg[br], specialised != 0, lds, tab, p, lane, cur, fresh, rowpar, lme, erase, era_edges[br], plane_off);
                     else if (method == 5) cur = step<5>(deg[br], specialised != 0, lds, tab, p, lane, cur, fresh, rowpar, lme);
                     else if (oms) cur = step<1>(deg[br], specialised != 0, lds, tab, p, lane, cur, fresh, rowpar, lme);
                     else return LNSFAID_E_INVAL;

@@ -496,3 +496,43 @@ def test_pinned_host_buffers_take_the_pipelined_path(abi, lib, code50):
     d.close()
     assert np.array_equal(dst, ref) and np.array_equal(st, ref_st)
     assert lib.lnsfaid_host_register(None, 16) != 0
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_ef_elimination_variants_of_decode_faid(abi, lib, code50, mode):
+    """SURVEY.md 8(f) N3, last item: EF_ELIMINATION 1 (error-floor tables) and 2 (+ erasure of the V2C of weight-3 nodes with
+    three unsatisfied checks, CDecoder_FAID.cpp:673-680) of Decode_FAID on the GPU against the oracle: channel batches and nearly
+    clean frames with a few confident errors; hard decisions and (I, J) per group.  No reference output exists for these
+    compile-time variants (parity unpinned)."""
+    rng = np.random.default_rng(70 + mode)
+    N, K = code50.N, code50.K
+    ng = 4
+    llr = np.full((ng * 32, N), -3, dtype=np.int16) + rng.integers(-2, 3, size=(ng * 32, N))
+    for l in range(ng * 32):
+        nf = int(rng.integers(2, 24))
+        llr[l, rng.integers(17 * 256, 67 * 256, size=nf)] = rng.integers(3, 8, size=nf)
+    llr = np.clip(llr, -7, 7).astype(np.int8).reshape(ng, 32, N)
+    synth = np.concatenate([np.concatenate([g[:, :K].reshape(-1), g[:, K:].reshape(-1)]) for g in llr])
+    for max_iter, fix in ((10, oa.ReferenceChannel(code50, 137, 13.0).groups(3.55, ng)), (6, synth), (7, synth), (10, synth)):
+        cfg = abi.default_cfg(2, max_iter)
+        assert lib.lnsfaid_cfg_ef_elimination(cfg, mode) == 0
+        ref, rst = oa.decode_mt(code50, cfg, fix, ng)
+        d = abi.Decoder(code50, cfg, 0, ng)
+        assert d.rows_per_lane() == 4
+        with pytest.raises(RuntimeError):
+            d.select_kernel(2)  # these variants exist in the four-rows-per-lane kernel only
+        out, st = d.decode(fix, ng)
+        d.close()
+        assert np.array_equal(out, ref) and np.array_equal(st, rst)
+    if mode == 2:  # the erasure changes what is decoded on the synthetic batch (else the test would prove nothing about it)
+        cfg = abi.default_cfg(2, 6)
+        assert lib.lnsfaid_cfg_ef_elimination(cfg, 2) == 0
+        with_erasure, st2 = oa.decode_mt(code50, cfg, synth, ng)
+        cfg.ef_elimination = 1
+        without, st1 = oa.decode_mt(code50, cfg, synth, ng)
+        assert not (np.array_equal(with_erasure, without) and np.array_equal(st1, st2))
+    cfg = abi.default_cfg(2, 10)
+    assert lib.lnsfaid_cfg_ef_elimination(cfg, 2) == 0
+    cfg.v2c_map_ef[0][2][5] = 7  # error-floor tables must be uniform over the weight classes for these variants
+    with pytest.raises(RuntimeError):
+        abi.Decoder(code50, cfg, 0, 1)

@@ -233,3 +233,27 @@ def test_general_channel_restatement(code50, encoder, mod_type, interleave):
     lib_cfg = oa.pyabi.default_cfg(2, 10)
     dec, _ = oa.Oracle(code50, lib_cfg, "avx2").decode(out, 1)
     assert np.array_equal(dec.reshape(32, code50.N), frames)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_ef_elimination_variants_of_decode_faid_port_equals_oracle(abi, lib, code50, mode):
+    """EF_ELIMINATION 1 / 2 of Decode_FAID (CDecoder_FAID.cpp:6, :192-203, :673-680; dead in the shipped build, so no reference
+    output exists for them: PARITY UNPINNED): the scalar oracle and the AVX2 port, written independently, agree on channel
+    batches around the waterfall and on nearly clean frames with a few confident errors (where the erasure acts)."""
+    rng = np.random.default_rng(40 + mode)
+    N, K = code50.N, code50.K
+    batches = [(10, oa.ReferenceChannel(code50, 131, 13.0).groups(3.55, 3))]
+    llr = np.full((3 * 32, N), -3, dtype=np.int16) + rng.integers(-2, 3, size=(3 * 32, N))
+    for l in range(3 * 32):
+        llr[l, rng.integers(17 * 256, 67 * 256, size=8)] = rng.integers(3, 8, size=8)
+    llr = np.clip(llr, -7, 7).astype(np.int8).reshape(3, 32, N)
+    batches.append((6, np.concatenate([np.concatenate([g[:, :K].reshape(-1), g[:, K:].reshape(-1)]) for g in llr])))
+    for max_iter, fix in batches:
+        cfg = abi.default_cfg(2, max_iter)
+        assert lib.lnsfaid_cfg_ef_elimination(cfg, mode) == 0
+        assert (cfg.floor_err_count, cfg.floor_iter_thresh) == ((100, 6) if mode == 1 else (20, 6))
+        a, sa = oa.Oracle(code50, cfg).decode(fix, 3)
+        b, sb = oa.decode_mt(code50, cfg, fix, 3, kind="avx2")
+        assert np.array_equal(a, b) and np.array_equal(sa, sb)
+    cfg = abi.default_cfg(5, 10)
+    assert lib.lnsfaid_cfg_ef_elimination(cfg, 2) != 0  # Decode_FAID only

@@ -39,3 +39,42 @@ def test_swar_layer_step_equals_the_oracle(abi, code50, method, eb_n0, n_iter, s
     assert bad.size == 0, "En differs at %s: oracle %s, layer step %s" % (bad[:8].tolist(), ref[bad[:8]].tolist(), got[bad[:8]].tolist())
     if n_iter == 10 and eb_n0 >= 3.4:
         assert np.abs(ref).max() == 31  # these batches reach the saturation limit: the merged clamp is exercised
+
+
+def _few_confident_errors(code50, rng, nflip, amp, noise):
+    """All-zero codeword received almost cleanly, plus a few weight-3 variable nodes with the wrong sign at high confidence:
+    few unsatisfied checks, and nodes whose three checks all fail - what EF_ELIMINATION 2 reacts to."""
+    N, K = code50.N, code50.K
+    llr = np.full((32, N), -amp, dtype=np.int16) + rng.integers(-noise, noise + 1, size=(32, N))
+    for l in range(32):
+        llr[l, rng.integers(17 * 256, 67 * 256, size=nflip)] = rng.integers(3, 8, size=nflip)
+    llr = np.clip(llr, -7, 7).astype(np.int8)
+    return np.concatenate([llr[:, :K].reshape(-1), llr[:, K:].reshape(-1)])
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("nflip,amp,noise,max_iter,n_iter", [(3, 4, 2, 6, 3), (6, 3, 2, 6, 4), (12, 3, 3, 7, 7), (20, 2, 2, 6, 6)])
+def test_swar_layer_step_with_ef_elimination(abi, lib, code50, mode, nflip, amp, noise, max_iter, n_iter):
+    """EF_ELIMINATION 1 (error-floor tables) and 2 (tables + erasure, CDecoder_FAID.cpp:673-680) of Decode_FAID: the layer
+    step's erasing variant against the oracle's statement-by-statement restatement."""
+    olib = oa.load()
+    olib.lnsfaid_oracle_layered_en.restype = C.c_int
+    olib.lnsfaid_oracle_layered_en.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    em = C.CDLL(EMU)
+    em.swar_emul_layered.restype = C.c_int
+    em.swar_emul_layered.argtypes = [C.POINTER(abi.Code), C.POINTER(abi.Cfg), C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    fix = _few_confident_errors(code50, np.random.default_rng(10 * nflip + mode), nflip, amp, noise)
+    cfg = abi.default_cfg(2, max_iter)
+    assert lib.lnsfaid_cfg_ef_elimination(cfg, mode) == 0
+    o = oa.Oracle(code50, cfg)
+    ref = np.empty(32 * code50.N, dtype=np.int8)
+    got = np.empty(32 * code50.N, dtype=np.int8)
+    assert olib.lnsfaid_oracle_layered_en(o.h, fix.ctypes.data, n_iter, ref.ctypes.data) == 0
+    assert em.swar_emul_layered(C.byref(code50.code), C.byref(cfg), fix.ctypes.data, n_iter, 0, got.ctypes.data) == 0
+    assert np.array_equal(ref, got)
+    if mode == 2 and nflip <= 6:  # (more wrong nodes than that mean 20 or more unsatisfied checks: outside the rule) the erasure really happened: without it (tables only, same window) En comes out differently
+        cfg.ef_elimination = 1
+        o1 = oa.Oracle(code50, cfg)
+        other = np.empty_like(ref)
+        assert olib.lnsfaid_oracle_layered_en(o1.h, fix.ctypes.data, n_iter, other.ctypes.data) == 0
+        assert not np.array_equal(other, ref)
