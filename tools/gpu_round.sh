@@ -1,9 +1,13 @@
-# full evidence run for a round tag: GPU tests, bench (unprofiled), rocprofv3 kernel-trace stats, PMC traffic
+# full evidence run for a round tag (on the GPU box: gpurun -- 'bash tools/gpu_round.sh <tag>'): GPU tests, bench (unprofiled),
+# rocprofv3 kernel-trace stats, HBM and SQ counters in separate --pmc passes, the DecodeMethod 5 / 16-QAM bench line.
+# Afterwards, here: python tools/parse_pmc.py gpurun_out/pmc_<tag> <tag>; python tools/parse_pmc_sq.py gpurun_out/pmc_sq_<tag> <tag>
 set -x
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gputests_$TAG.log 2>&1; tail -3 gpurun_out/gputests_$TAG.log
 timeout -k 10 600 python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_$TAG.json
-python -c "import json; d=json.load(open('gpurun_out/bench_$TAG.json')); print(d['value'], d['ms_per_step'], d['roofline'], d.get('points'), d.get('cpu_baseline'))"
+python -c "import json; d=json.load(open('gpurun_out/bench_$TAG.json')); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d.get('points'), d.get('cpu_baseline'))"
+timeout -k 10 300 python bench.py --method 5 --mod-type 4 --scale 12.5 --eb-n0 8.1 --no-cpu 2>/dev/null | tail -1 > gpurun_out/bench_cfg5_$TAG.json
 bash tools/gpu_profile.sh $TAG
 bash tools/gpu_pmc.sh $TAG
+bash tools/gpu_pmc_sq.sh $TAG

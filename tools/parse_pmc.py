@@ -17,11 +17,16 @@ src, tag = sys.argv[1], sys.argv[2]
 N, K = 17664, 14592
 
 
+kernel_name = [None]
+
+
 def load(sub):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     grid = {}
     for r in csv.DictReader(open(os.path.join(src, sub, "p_counter_collection.csv"))):
         name = "decode" if "lnsfaid_decode" in r["Kernel_Name"] else ("count" if "lnsfaid_count" in r["Kernel_Name"] else None)
+        if name == "decode":
+            kernel_name[0] = r["Kernel_Name"]
         if name:
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
             grid[name] = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
@@ -31,7 +36,7 @@ def load(sub):
 fetch, grid = load("fetch")
 write, _ = load("write")
 mean = lambda v: sum(v) / len(v)
-n_cw = grid["decode"]
+n_cw = grid["decode"]  # one workgroup per codeword in both decode kernels
 dec_fetch_kib = mean(fetch["decode"]["FETCH_SIZE"])
 dec_write_kib = mean(write["decode"]["WRITE_SIZE"])
 cnt_fetch_kib = mean(fetch["count"]["FETCH_SIZE"])
@@ -41,7 +46,7 @@ corrected_read = dec_fetch_kib * 1024.0 * 2.0
 out = {
     "tag": tag,
     "kernel_source_hash": open(os.path.join(src, "kernel_source_hash.txt")).read().strip(),
-    "kernel": "lnsfaid_decode_kernel<2, true>",
+    "kernel": kernel_name[0],
     "codewords_per_launch": n_cw,
     "FETCH_SIZE_KiB_raw": dec_fetch_kib,
     "WRITE_SIZE_KiB_raw": dec_write_kib,
