@@ -209,12 +209,14 @@ struct SwUpd {
     uint32_t oc[2], qc[2], lc[2], hl[2], ll[2]; /* [1]: chosen where the mask is 0xff, [0]: where it is 0x00 */
 };
 /* c: magnitude bytes (0..7); flip: byte mask, 0xff where mask polarity is inverted (row parity F) */
+/* `bias`: what the caller's tb carries on top of t + 128 per byte (FAID keeps the v_perm selector's 0 / 2 / 4 / 6 in it, see
+ * pass 1): folded into the three constants that meet tb */
 template <bool MINSUM>
-SW_FN SwUpd sw_update_consts(uint32_t c, uint32_t flip)
+SW_FN SwUpd sw_update_consts(uint32_t c, uint32_t flip, uint32_t bias)
 {
-    const uint32_t oc_p = 0x20202020u - c, oc_n = MINSUM ? 0x20202020u + c : 0x20202020u; /* over  <=> t > hi' : tb - (hi' + 1) >= 128 */
-    const uint32_t qc_p = 0x1f1f1f1fu, qc_n = 0x1f1f1f1fu - c;                            /* under <=> t < lo' : tb - lo' < 128        */
-    const uint32_t lc_p = 0x08080808u - c, lc_n = 0x08080808u + c;                        /* Eb' = tb - (8 - L)                        */
+    const uint32_t oc_p = 0x20202020u + bias - c, oc_n = (MINSUM ? 0x20202020u + c : 0x20202020u) + bias; /* over  <=> t > hi' : tb - (hi' + 1) >= 128 */
+    const uint32_t qc_p = 0x1f1f1f1fu - bias, qc_n = 0x1f1f1f1fu - bias - c;              /* under <=> t < lo' : tb - lo' < 128        */
+    const uint32_t lc_p = 0x08080808u + bias - c, lc_n = 0x08080808u + bias + c;          /* Eb' = tb - (8 - L)                        */
     const uint32_t hl_p = 0x97979797u, hl_n = MINSUM ? 0x97979797u : 0x97979797u - c;     /* hi' + L + 120                             */
     const uint32_t ll_p = 0x59595959u + c, ll_n = 0x59595959u;                            /* lo' + L + 120                             */
     SwUpd u;
@@ -275,7 +277,10 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     /* ---- the row's old messages: +-c2 on every edge (8 +- c2 as a v_perm table indexed 2 k + negative) ---- */
     const uint32_t c2o = cur.cw & 0x07070707u, c1o = (cur.cw >> 3) & 0x07070707u;
     const uint32_t kp = 0x08080808u - c2o, kn = 0x08080808u + c2o;
-    const uint32_t kt_lo = sw_perm(kn, kp, 0x05010400u), kt_hi = sw_perm(kn, kp, 0x07030602u);
+    /* FAID: tb = En + 120 + K + selector, with the selector's row part (0 / 2 / 4 / 6 per byte) folded into the table, so that
+     * tb - selector = t + 128 - b is the back-tracked sign word in ONE subtraction; pass 2 compensates in its constants */
+    const uint32_t bias = MINSUM ? 0u : 0x06040200u;
+    const uint32_t kt_lo = sw_perm(kn, kp, 0x05010400u) + (MINSUM ? 0u : 0x02020000u), kt_hi = sw_perm(kn, kp, 0x07030602u) + (MINSUM ? 0u : 0x06060404u);
     /* thermometer code of min(|t|, 7); entry 7 equals what v_perm returns for a saturated selector */
     const uint32_t tt_lo = sw_vconst(0x07030100u), tt_hi = sw_vconst(0xff3f1f0fu);
 
@@ -322,16 +327,15 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
      * different edges and do not wait for each other (two waves per SIMD cannot hide that latency). */
 #pragma unroll
     for (int j0 = 0; j0 < NJ; j0 += SW_ILP) {
-        uint32_t r_[SW_ILP], x_[SW_ILP], k_[SW_ILP], a_[SW_ILP], i_[SW_ILP], u_[SW_ILP];
+        uint32_t r_[SW_ILP], x_[SW_ILP], s_[SW_ILP], k_[SW_ILP], a_[SW_ILP], i_[SW_ILP], u_[SW_ILP];
 #define SW_EDGES(...) _Pragma("unroll") for (int g = 0; g < SW_ILP; ++g) { const int j = j0 + g; if (j < NJ && (DEG > 0 || j < deg)) { __VA_ARGS__ } }
         SW_EDGES(r_[g] = sw_alignbyte(ld[j], ld[j], rq[j]);)                                  /* byte k = En + 120 of row k */
         SW_EDGES(x_[g] = (j & 7) ? cur.x[j >> 3] >> (j & 7) : cur.x[j >> 3];)
-        SW_EDGES(k_[g] = sw_bitop3<SW_TT_ANDOR>(x_[g], c01, c0642);)
-        SW_EDGES(k_[g] = sw_perm(kt_hi, kt_lo, k_[g]);)
+        SW_EDGES(s_[g] = sw_bitop3<SW_TT_ANDOR>(x_[g], c01, c0642);)
+        SW_EDGES(k_[g] = sw_perm(kt_hi, kt_lo, s_[g]);)
         SW_EDGES(tb[j] = r_[g] + k_[g];)                          /* t + 128, VECTOR_SUB_AND_SATURATE comes in pass 2 */
-        /* FAID: a zero V2C takes the sign of En (CDecoder_FAID.cpp:682); En == Lold there, so it is the stored sign */
-        SW_EDGES(x_[g] &= c01;)                                   /* b: the old message on this edge is negative */
         if (ERA) {
+            SW_EDGES(x_[g] &= c01;)                               /* b: the old message on this edge is negative */
             SW_EDGES(
                 if ((era_edges >> j) & 1u) {
                     uint32_t em = 0, match = 0;
@@ -343,19 +347,21 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
                     }
                     const uint32_t en_true = r_[g] - (padd & match) + (psub & match);
                     const uint32_t neg01 = ~((en_true + 0x08080808u) >> 7) & c01;      /* En < 0 */
-                    tb[j] = sw_bitop3<SW_TT_SEL>(em, c80, tb[j]);                      /* vContr = 0 */
+                    tb[j] = sw_bitop3<SW_TT_SEL>(em, c80 + bias, tb[j]);               /* vContr = 0 */
                     x_[g] = sw_bitop3<SW_TT_SEL>(em, neg01, x_[g]);                    /* its sign: the sign of En */
                 })
         }
-        SW_EDGES(ts[j] = MINSUM ? tb[j] : tb[j] - x_[g];)
+        /* FAID: a zero V2C takes the sign of En (CDecoder_FAID.cpp:682); En == Lold there, so it is the stored sign b: bit 7 of
+         * t + 128 - b.  k_ still holds the selector 2 k + b of the edge (the erasing variant rebuilds it from its own b) */
+        SW_EDGES(ts[j] = MINSUM ? tb[j] : tb[j] - (ERA ? (x_[g] | c0642) : s_[g]);)
         SW_EDGES(ms[j] = sw_mask7(ts[j], sel_sign);)
         /* |t| -> min(|t|, 7) -> thermometer.  With m = 0xff where the (back-tracked) sign is "not negative":
          *   not negative: ts ^ 0x80 = t - b,  |t| = that + b          negative: ts ^ 0x7f = -t - 1 + b,  |t| = that + 1 - b
          * (b = 0 for the min-sum decoders); 0x78 is added on top so that |t| >= 8 reaches bit 7, which the table look-up
          * turns into the saturated code */
         SW_EDGES(a_[g] = sw_bitop3<SW_TT_XOR3>(ts[j], c7f, ms[j]);)
-        SW_EDGES(i_[g] = MINSUM ? sw_bitop3<SW_TT_NANDOR>(ms[j], c01, c78) : (sw_bitop3<SW_TT_XNOR_AND>(x_[g], ms[j], c01) | c78);)
-        SW_EDGES(a_[g] = (a_[g] + i_[g]) & 0x87878787u;)
+        SW_EDGES(i_[g] = MINSUM ? sw_bitop3<SW_TT_NANDOR>(ms[j], c01, c78) : sw_bitop3<SW_TT_XNOR_AND>(x_[g], ms[j], c01);)
+        SW_EDGES(a_[g] = (MINSUM ? a_[g] + i_[g] : a_[g] + i_[g] + c78) & 0x87878787u;)     /* v_add3_u32 */
         SW_EDGES(u_[g] = sw_perm(tt_hi, tt_lo, a_[g]);)
         SW_EDGES(
             if (j & 1) sx = sw_bitop3<SW_TT_XOR3>(sx, ts[j - 1], ts[j]); else if (j == (DEG > 0 ? DEG : deg) - 1) sx ^= ts[j];
@@ -426,7 +432,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
         xb |= ((xw >> ((ik & 7u) + 8u * (uint32_t)k)) & 1u) << (8 * k); /* old message on that edge negative */
     }
     const uint32_t selA = xb | c0642;
-    uint32_t tbA = gb + sw_perm(kt_hi, kt_lo, selA);
+    uint32_t tbA = gb + sw_perm(kt_hi, kt_lo, selA); /* carries `bias` like tb[] */
     if (ERA) { /* the arg-min edge of a row may be an erased one (a V2C of 0 usually IS the minimum) */
         uint32_t em = 0, match = 0;
 #pragma unroll
@@ -437,17 +443,17 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
             match |= (!fresh && pa[k] == pold) ? (0xffu << (8 * k)) : 0u;
         }
         const uint32_t en_true = gb - (padd & match) + (psub & match);
-        tbA = sw_bitop3<SW_TT_SEL>(em, c80, tbA);
+        tbA = sw_bitop3<SW_TT_SEL>(em, c80 + bias, tbA);
         xb = sw_bitop3<SW_TT_SEL>(em, ~((en_true + 0x08080808u) >> 7) & c01, xb);
     }
-    const uint32_t tsA = MINSUM ? tbA : tbA - xb;
+    const uint32_t tsA = MINSUM ? tbA : tbA - (xb | c0642);
     const uint32_t msA = sw_mask7(tsA, sel_sign);
-    const SwUpd u1 = sw_update_consts<MINSUM>(c1n, fm);
+    const SwUpd u1 = sw_update_consts<MINSUM>(c1n, fm, bias);
     const uint32_t enA = sw_update(tbA, msA, u1, sel_sign);
     const uint32_t negA = ~(msA ^ fm); /* byte mask: the new message on the arg-min edge is negative */
 
     /* ---- pass 2 (CDecoder_FAID.cpp:909-929, CDecoder_OMS.cpp:452-471): every edge as if it carried c2 ---- */
-    const SwUpd u2 = sw_update_consts<MINSUM>(c2n, fm);
+    const SwUpd u2 = sw_update_consts<MINSUM>(c2n, fm, bias);
     uint32_t ns[3] = { 0u, 0u, 0u };
     uint32_t cbit[8];
 #pragma unroll
