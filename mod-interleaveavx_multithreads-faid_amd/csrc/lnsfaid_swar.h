@@ -118,7 +118,7 @@ SW_FN uint32_t sw_vconst(uint32_t k)
 {
 #if SW_DEV
     uint32_t r;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(k));
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(k)); /* not volatile: the compiler may hoist it out of the layer / iteration loops */
     return r;
 #else
     return k;
@@ -402,7 +402,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
 #pragma unroll
     for (int b = 0; b < 5; ++b) {
         const uint32_t dd = sw_bitop3<SW_TT_XORAND>(ta[b], t1, c7f);
-        idx |= ((dd + c7f) & c80) >> (7 - b);
+        idx = sw_bitop3<SW_TT_ANDNOT_OR>(idx, (dd + c7f) >> (7 - b), 0x01010101u << b); /* bit 7 of every byte of dd + 0x7f: dd != 0 */
     }
     /* a tie leaves the AND of the tied indices: still an edge of the row, and in a tie c1 == c2 */
 
@@ -422,14 +422,19 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t ik = (idx >> (8 * k)) & 31u;
 #ifdef SW_EXP_NO_ARGMIN
         gb |= (ld[k] & 0xffu) << (8 * k);
 #else
         gb |= lds.rd8(pa[k]) << (8 * k);
 #endif
-        const uint32_t xw = ik < 8u ? cur.x[0] : (ik < 16u ? cur.x[1] : cur.x[2]); /* selects: a dynamic index would go through scratch */
-        xb |= ((xw >> ((ik & 7u) + 8u * (uint32_t)k)) & 1u) << (8 * k); /* old message on that edge negative */
+    }
+    /* the arg-min edges as one-hot bits inside their 8-edge word (byte k: 1 << (index mod 8)) and the word they are in
+     * (index div 8 = 0, 1, 2) as byte masks, all four rows at once */
+    const uint32_t oh8 = sw_perm(sw_vconst(0x80402010u), sw_vconst(0x08040201u), idx & 0x07070707u);
+    const uint32_t in1 = sw_mask7(idx << 4, sel_sign), in2 = sw_mask7(idx << 3, sel_sign); /* index bit 3 / bit 4 */
+    {   /* old message on that edge negative: bit (index mod 8) of byte k of sign word (index div 8) */
+        const uint32_t w = sw_bitop3<SW_TT_SEL>(in2, cur.x[2], sw_bitop3<SW_TT_SEL>(in1, cur.x[1], cur.x[0]));
+        xb = (((w & oh8) + c7f) & c80) >> 7;
     }
     const uint32_t selA = xb | c0642;
     uint32_t tbA = gb + sw_perm(kt_hi, kt_lo, selA); /* carries `bias` like tb[] */
@@ -448,9 +453,10 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     }
     const uint32_t tsA = MINSUM ? tbA : tbA - (xb | c0642);
     const uint32_t msA = sw_mask7(tsA, sel_sign);
-    const SwUpd u1 = sw_update_consts<MINSUM>(c1n, fm, bias);
-    const uint32_t enA = sw_update(tbA, msA, u1, sel_sign);
     const uint32_t negA = ~(msA ^ fm); /* byte mask: the new message on the arg-min edge is negative */
+    /* used once: flip = 0 leaves [1] = "not negative" constants, [0] = "negative" ones, picked by the combined mask */
+    const SwUpd u1 = sw_update_consts<MINSUM>(c1n, 0u, bias);
+    const uint32_t enA = sw_update(tbA, ~negA, u1, sel_sign);
 
     /* ---- pass 2 (CDecoder_FAID.cpp:909-929, CDecoder_OMS.cpp:452-471): every edge as if it carried c2 ---- */
     const SwUpd u2 = sw_update_consts<MINSUM>(c2n, fm, bias);
@@ -497,15 +503,10 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
         /* A zero message has no sign: stored as "not negative" so that the next iteration's back-track reads
          * "Lmn < 0" straight from the bit.  c2 == 0 zeroes every message of the row but the arg-min's. */
         const uint32_t z2 = sw_zero_mask(c2n, sel_sign), nz1 = ~sw_zero_mask(c1n, sel_sign);
-        uint32_t oh[3] = { 0u, 0u, 0u };
+        const uint32_t keep = oh8 & nz1; /* the arg-min edge's bit survives where its message c1 is not zero */
+        const uint32_t oh[3] = { keep & ~(in1 | in2), keep & in1, keep & in2 };
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t ik = (idx >> (8 * k)) & 31u;
-            const uint32_t bit = 1u << ((ik & 7u) + 8u * (uint32_t)k);
-            oh[0] |= (ik >> 3) == 0u ? bit : 0u; oh[1] |= (ik >> 3) == 1u ? bit : 0u; oh[2] |= (ik >> 3) == 2u ? bit : 0u;
-        }
-#pragma unroll
-        for (int g = 0; g < 3; ++g) out.x[g] &= ~z2 | (oh[g] & nz1);
+        for (int g = 0; g < 3; ++g) out.x[g] &= ~z2 | oh[g];
     }
     out.cw = c2n | (c1n << 3) | (negA & 0x40404040u);
     out.pa[0] = pa[0] | (pa[1] << 16);
