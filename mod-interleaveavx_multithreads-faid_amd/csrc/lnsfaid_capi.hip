@@ -125,6 +125,8 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
             out->circ[br][j].sb = (uint32_t)cb * (uint32_t)Z + (uint32_t)sh;
             out->sbtab[br][LF_JCODE_A(j)] = out->sbtab[br][LF_JCODE_B(j)] = out->circ[br][j].sb;
             out->sbplain[br][j] = out->circ[br][j].sb;
+            out->s4tab[br][j] = ((uint32_t)sh) << 2;
+            out->cbtab[br][j] = (uint32_t)cb * (uint32_t)Z;
             if (out->col_weight[cb] >= LF_MAX_COLW) return LNSFAID_E_CODE;
             out->colcirc[cb][out->col_weight[cb]++] = (uint32_t)br | ((uint32_t)sh << 8);
         }

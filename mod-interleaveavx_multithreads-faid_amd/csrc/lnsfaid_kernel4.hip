@@ -28,6 +28,10 @@ struct DevTab4 {
     int br;
     uint32_t sbv; /* lane j < 32: block column * 256 + shift of edge j of this layer */
     __device__ __forceinline__ uint32_t sb(int j) const { return c->circ[br][j].sb; }
+    /* the same split on the host (4 * shift, block column * 256): contiguous tables, so the 23 values of a layer arrive in a
+     * few wide scalar loads and no scalar arithmetic is left per edge */
+    __device__ __forceinline__ uint32_t s4(int j) const { return c->s4tab[br][j]; }
+    __device__ __forceinline__ uint32_t cb256(int j) const { return c->cbtab[br][j]; }
     __device__ __forceinline__ uint32_t sb_dyn(uint32_t idx) const
     {
         return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)sbv);

@@ -249,7 +249,8 @@ SW_FN uint32_t sw_plane_bit(const SwLds& lds, uint32_t era_plane, uint32_t a)
 }
 
 /* ---- one layer -----------------------------------------------------------------------------------------------------
- * Tab: tab.sb(j) = block column * 256 + shift of edge j (uniform), tab.sb_dyn(idx) the same for a per-lane edge index.
+ * Tab: tab.s4(j) = 4 * shift and tab.cb256(j) = block column * 256 of edge j (uniform), tab.sb_dyn(idx) = block column * 256 +
+ * shift for a per-lane edge index.
  * rowpar: byte mask, 0xff in byte k if the syndrome bit of row i + 64 k is set (only read by the OMS selective offset
  * and the 2B1C error-floor tables); lme: unsat < floor_err_count for this codeword.
  * DecodeMethod 0 (NMS) is not built here: its minima run over |t| up to 31, more levels than the 8-entry thermometer holds. */
@@ -270,9 +271,9 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     const uint32_t sel_sign = sw_vconst(SW_SEL_SIGN);
     const uint32_t tid4 = lane << 2;
     /* the layer's circulants first (scalar loads share the LDS counter: in flight together with LDS reads they force full drains) */
-    uint32_t sbj[NJ];
+    uint32_t s4j[NJ], cbj[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) sbj[j] = (DEG > 0 || j < deg) ? tab.sb(j) : 0u;
+    for (int j = 0; j < NJ; ++j) { s4j[j] = (DEG > 0 || j < deg) ? tab.s4(j) : 0u; cbj[j] = (DEG > 0 || j < deg) ? tab.cb256(j) : 0u; }
 
     /* ---- the row's old messages: +-c2 on every edge (8 +- c2 as a v_perm table indexed 2 k + negative) ---- */
     const uint32_t c2o = cur.cw & 0x07070707u, c1o = (cur.cw >> 3) & 0x07070707u;
@@ -307,13 +308,12 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         if (DEG > 0 || j < deg) {
-            const uint32_t sb = sbj[j];
-            const uint32_t x4 = tid4 + ((sb & 255u) << 2);
+            const uint32_t x4 = tid4 + s4j[j];
 #if SW_DEV
             uint32_t a;
-            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(x4), "v"(cfc), "s"(sb & ~255u));
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(x4), "v"(cfc), "s"(cbj[j]));
 #else
-            const uint32_t a = (x4 & cfc) | (sb & ~255u);
+            const uint32_t a = (x4 & cfc) | cbj[j];
 #endif
             ad[j] = a; rq[j] = x4 >> 8;
         }
@@ -410,7 +410,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     uint32_t pa[4], sbk[4], gb = 0, xb = 0;
 #pragma unroll
 #ifdef SW_EXP_NO_ARGMIN /* timing experiment only: results are wrong */
-    for (int k = 0; k < 4; ++k) sbk[k] = sbj[k];
+    for (int k = 0; k < 4; ++k) sbk[k] = cbj[k] | (s4j[k] >> 2);
 #else
     for (int k = 0; k < 4; ++k) sbk[k] = tab.sb_dyn((idx >> (8 * k)) & 31u);
 #endif

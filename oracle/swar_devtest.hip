@@ -38,6 +38,8 @@ struct TabDev {
     const uint32_t* row; /* global: sb of the layer's edges */
     uint32_t sbv;
     __device__ __forceinline__ uint32_t sb(int j) const { return __builtin_amdgcn_readfirstlane(row[j]); }
+    __device__ __forceinline__ uint32_t s4(int j) const { return (sb(j) & 255u) << 2; }
+    __device__ __forceinline__ uint32_t cb256(int j) const { return sb(j) & ~255u; }
     __device__ __forceinline__ uint32_t sb_dyn(uint32_t idx) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)sbv); }
 };
 

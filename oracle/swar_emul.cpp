@@ -17,6 +17,8 @@ namespace {
 struct HostTab {
     const uint32_t* row; /* sb of the layer's edges */
     uint32_t sb(int j) const { return row[j]; }
+    uint32_t s4(int j) const { return (row[j] & 255u) << 2; }
+    uint32_t cb256(int j) const { return row[j] & ~255u; }
     uint32_t sb_dyn(uint32_t j) const { return row[j]; }
 };
 
