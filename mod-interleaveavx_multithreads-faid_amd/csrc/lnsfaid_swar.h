@@ -211,7 +211,7 @@ struct SwUpd {
 /* c: magnitude bytes (0..7); flip: byte mask, 0xff where mask polarity is inverted (row parity F) */
 /* `bias`: what the caller's tb carries on top of t + 128 per byte (FAID keeps the v_perm selector's 0 / 2 / 4 / 6 in it, see
  * pass 1): folded into the three constants that meet tb */
-template <bool MINSUM>
+template <bool MINSUM, bool FLIP = true>
 SW_FN SwUpd sw_update_consts(uint32_t c, uint32_t flip, uint32_t bias)
 {
     const uint32_t oc_p = 0x20202020u + bias - c, oc_n = (MINSUM ? 0x20202020u + c : 0x20202020u) + bias; /* over  <=> t > hi' : tb - (hi' + 1) >= 128 */
@@ -220,6 +220,11 @@ SW_FN SwUpd sw_update_consts(uint32_t c, uint32_t flip, uint32_t bias)
     const uint32_t hl_p = 0x97979797u, hl_n = MINSUM ? 0x97979797u : 0x97979797u - c;     /* hi' + L + 120                             */
     const uint32_t ll_p = 0x59595959u + c, ll_n = 0x59595959u;                            /* lo' + L + 120                             */
     SwUpd u;
+    if (!FLIP) { /* the caller's mask already is "new message not negative" */
+        u.oc[1] = oc_p; u.oc[0] = oc_n; u.qc[1] = qc_p; u.qc[0] = qc_n; u.lc[1] = lc_p; u.lc[0] = lc_n;
+        u.hl[1] = hl_p; u.hl[0] = hl_n; u.ll[1] = ll_p; u.ll[0] = ll_n;
+        return u;
+    }
     u.oc[1] = sw_bitop3<SW_TT_SEL>(flip, oc_n, oc_p); u.oc[0] = sw_bitop3<SW_TT_SEL>(flip, oc_p, oc_n);
     u.qc[1] = sw_bitop3<SW_TT_SEL>(flip, qc_n, qc_p); u.qc[0] = sw_bitop3<SW_TT_SEL>(flip, qc_p, qc_n);
     u.lc[1] = sw_bitop3<SW_TT_SEL>(flip, lc_n, lc_p); u.lc[0] = sw_bitop3<SW_TT_SEL>(flip, lc_p, lc_n);
@@ -455,7 +460,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     const uint32_t msA = sw_mask7(tsA, sel_sign);
     const uint32_t negA = ~(msA ^ fm); /* byte mask: the new message on the arg-min edge is negative */
     /* used once: flip = 0 leaves [1] = "not negative" constants, [0] = "negative" ones, picked by the combined mask */
-    const SwUpd u1 = sw_update_consts<MINSUM>(c1n, 0u, bias);
+    const SwUpd u1 = sw_update_consts<MINSUM, false>(c1n, 0u, bias);
     const uint32_t enA = sw_update(tbA, ~negA, u1, sel_sign);
 
     /* ---- pass 2 (CDecoder_FAID.cpp:909-929, CDecoder_OMS.cpp:452-471): every edge as if it carried c2 ---- */
