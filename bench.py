@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # occupies its SIMD for 2 cycles at the full rate
 N_SIMD, CLOCK_GHZ, CYCLES_PER_WAVE64_VALU = 1024, 2.4, 2
 VALU_PEAK_GINSTR = N_SIMD * CLOCK_GHZ / CYCLES_PER_WAVE64_VALU
-KERNEL_SOURCES = ["lnsfaid_kernels.hip", "lnsfaid_device.h"]
+KERNEL_SOURCES = ["lnsfaid_kernel4.hip", "lnsfaid_swar.h", "lnsfaid_phases.h", "lnsfaid_kernels.hip", "lnsfaid_device.h"]
 
 
 def kernel_source_hash():

@@ -124,7 +124,7 @@ static int build_code(const lnsfaid_code* code, LfDevCode* out)
             prev_cb = cb;
             out->circ[br][j].sb = (uint32_t)cb * (uint32_t)Z + (uint32_t)sh;
             out->sbtab[br][LF_JCODE_A(j)] = out->sbtab[br][LF_JCODE_B(j)] = out->circ[br][j].sb;
-            out->sbplain[br][j] = out->circ[br][j].sb;
+            out->sbplain[br][j] = (((uint32_t)cb * (uint32_t)Z) << 16) | (((uint32_t)sh) << 2);
             out->s4tab[br][j] = ((uint32_t)sh) << 2;
             out->cbtab[br][j] = (uint32_t)cb * (uint32_t)Z;
             if (out->col_weight[cb] >= LF_MAX_COLW) return LNSFAID_E_CODE;

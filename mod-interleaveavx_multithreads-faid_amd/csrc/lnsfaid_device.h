@@ -37,7 +37,7 @@ struct LfDevCode {
     int32_t deg[LF_MAX_BR];
     LfCirc circ[LF_MAX_BR][LF_MAX_DEG];
     uint32_t sbtab[LF_MAX_BR][64];            /* lane LF_JCODE_A(j) and lane LF_JCODE_B(j): circ[br][j].sb              */
-    uint32_t sbplain[LF_MAX_BR][32];          /* lane j: circ[br][j].sb (four-rows-per-lane kernel)                      */
+    uint32_t sbplain[LF_MAX_BR][32];          /* lane j: (block column * 256) << 16 | 4 * shift of edge j (four-rows kernel)  */
     uint32_t s4tab[LF_MAX_BR][LF_MAX_DEG];    /* 4 * shift of edge j: what lane i adds to 4 i to get its dword (scalar loads)    */
     uint32_t cbtab[LF_MAX_BR][LF_MAX_DEG];    /* block column * 256 of edge j: LDS base of the column                            */
     uint2 synw[LF_MAX_BR][LF_MAX_DEG][8];     /* syndrome walk, per (layer, circulant, 32-row word k): .x = LDS byte addresses of

@@ -26,15 +26,15 @@
 struct DevTab4 {
     CCode c;
     int br;
-    uint32_t sbv; /* lane j < 32: block column * 256 + shift of edge j of this layer */
+    uint32_t sbv; /* lane j < 32: (block column * 256) << 16 | 4 * shift of edge j of this layer */
     __device__ __forceinline__ uint32_t sb(int j) const { return c->circ[br][j].sb; }
     /* the same split on the host (4 * shift, block column * 256): contiguous tables, so the 23 values of a layer arrive in a
      * few wide scalar loads and no scalar arithmetic is left per edge */
     __device__ __forceinline__ uint32_t s4(int j) const { return c->s4tab[br][j]; }
     __device__ __forceinline__ uint32_t cb256(int j) const { return c->cbtab[br][j]; }
-    __device__ __forceinline__ uint32_t sb_dyn(uint32_t idx) const
+    __device__ __forceinline__ uint32_t sb_dyn4(uint32_t idx4) const
     {
-        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)sbv);
+        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)idx4, (int)sbv);
     }
 };
 
@@ -163,7 +163,7 @@ __device__ void build_erasure_plane4(CCode c, const LfDevCode* gc, uint32_t* pla
 
 /* ---- one layered iteration (lnsfaid_swar.h does the rows) ---- */
 template <int METHOD, bool ERA>
-__device__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, SwRow* __restrict__ rows, int lane, int it, const uint32_t* sP,
+__device__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, const SwK& K, SwRow* __restrict__ rows, int lane, int it, const uint32_t* sP,
                            bool have_par, bool lme, uint32_t era_plane)
 {
     const bool fresh = (it == 1); /* no iteration has run yet: every Lmn is still 0, nothing in HBM */
@@ -200,10 +200,10 @@ __device__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, SwRow* __restri
         tab.c = c; tab.br = br; tab.sbv = tabv;
         SwRow st;
         const uint32_t era_edges = ERA ? c->era_edges[br] : 0u;
-        if (ERA) st = sw_layer_step<METHOD, 0, ERA>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme, era_edges, era_plane); /* rare: one instance */
-        else if (deg == 23) st = sw_layer_step<METHOD, 23>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
-        else if (deg == 22) st = sw_layer_step<METHOD, 22>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
-        else st = sw_layer_step<METHOD, 0>(lds, tab, p, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
+        if (ERA) st = sw_layer_step<METHOD, 0, ERA>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme, era_edges, era_plane); /* rare: one instance */
+        else if (deg == 23) st = sw_layer_step<METHOD, 23>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
+        else if (deg == 22) st = sw_layer_step<METHOD, 22>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
+        else st = sw_layer_step<METHOD, 0>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
         /* take the prefetched data BEFORE the store is issued: vector-memory operations retire in order, so a wait for these
          * loads placed after the store would also wait for the store's round trip, once per layer */
         cur = fresh ? zero : nxt;
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
         __syncthreads();
     }
 
+    const SwK swk = sw_consts();
     {
         for (;;) {
             if (prog >= t_end) break; /* loops exhausted (also OMS after max_iter iterations) */
@@ -365,9 +366,9 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
                 if (METHOD == 2 && f->ef == 2 && needs_checksums && have_par && lme) {
                     /* EF_ELIMINATION 2 inside the window, few unsatisfied checks: this iteration erases (CDecoder_FAID.cpp:673-680) */
                     build_erasure_plane4(c, a.code, sHard, sP, f->W, tid);
-                    main_step4<METHOD, METHOD == 2>(c, f, a.code, g_rows, tid, prog, sP, true, lme, lf_lds_off_hard(N));
+                    main_step4<METHOD, METHOD == 2>(c, f, a.code, swk, g_rows, tid, prog, sP, true, lme, lf_lds_off_hard(N));
                 } else {
-                    main_step4<METHOD, false>(c, f, a.code, g_rows, tid, prog, sP, have_par && needs_checksums, lme, 0u);
+                    main_step4<METHOD, false>(c, f, a.code, swk, g_rows, tid, prog, sP, have_par && needs_checksums, lme, 0u);
                 }
                 prog++;
             } else {

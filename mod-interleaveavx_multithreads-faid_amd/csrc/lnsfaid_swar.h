@@ -125,6 +125,26 @@ SW_FN uint32_t sw_vconst(uint32_t k)
 #endif
 }
 
+/* the register constants of the layer step, built ONCE per kernel: inside the layer function they would sit in a conditionally
+ * executed block (the per-degree instances), out of which the compiler may not move an asm statement */
+struct SwK {
+    uint32_t c78, c0642, cfc, sel_sign, tt_lo, tt_hi, oh_lo, oh_hi;
+    uint32_t cbit[8]; /* 0x01010101 << e; [0] = 0x01010101, [7] = 0x80808080 */
+    uint32_t c7f;
+};
+SW_FN SwK sw_consts()
+{
+    SwK k;
+    k.c78 = sw_vconst(0x78787878u); k.c0642 = sw_vconst(0x06040200u); k.cfc = sw_vconst(0xfcu);
+    k.sel_sign = sw_vconst(0x0b090a08u);
+    /* thermometer code of min(|t|, 7); entry 7 equals what v_perm returns for a saturated selector */
+    k.tt_lo = sw_vconst(0x07030100u); k.tt_hi = sw_vconst(0xff3f1f0fu);
+    k.oh_lo = sw_vconst(0x08040201u); k.oh_hi = sw_vconst(0x80402010u);
+    for (int e = 0; e < 8; ++e) k.cbit[e] = sw_vconst(0x01010101u << e);
+    k.c7f = sw_vconst(0x7f7f7f7fu);
+    return k;
+}
+
 /* 0xff in every byte whose bit 7 is set, else 0x00 (two instructions: shift + v_perm with selectors 8..11) */
 SW_FN uint32_t sw_mask7(uint32_t x, uint32_t sel_sign) { return sw_perm(x, x << 8, sel_sign); }
 #define SW_SEL_SIGN 0x0b090a08u
@@ -202,47 +222,52 @@ SW_FN int sw_oms_offset(int x, bool window, bool F, int f1, int f2)
 }
 
 /* the two-stage saturating update En' = sat31(tc + L), tc = sat31(t) (FAID, CDecoder_FAID.cpp:672, :919-920) or
- * max(t, -31) (min-sum decoders, CDecoder_OMS.cpp:371, :466), written as ONE clamp of t with sign-dependent limits:
- *   L = +c : En' = c + clamp(t, -31, 31 - c)            L = -c : En' = -c + clamp(t, -31 + c, 31)   (31 + c: min-sum)
- * Per row the five byte constants below exist in a "new message not negative" (p) and a "negative" (n) version. */
+ * max(t, -31) (min-sum decoders, CDecoder_OMS.cpp:371, :466), written as ONE clamp whose limits do not depend on the sign of
+ * the new message L = +-c:
+ *   L = +c : En' = c + clamp(t, -31, 31 - c)        L = -c : En' = clamp(t - c, -31, 31 - c)      (min-sum, L = -c: ..., 31)
+ * i.e. z = t - (L < 0 ? c : 0), En' = clamp(z, -31, hi) + (L < 0 ? 0 : c): two sign-selected byte constants per edge (za, sb),
+ * the rest is per row.  Working byte zb = z + 159, so that "not under" is bit 7 of zb and "over" is bit 7 of zb - oc. */
 struct SwUpd {
-    uint32_t oc[2], qc[2], lc[2], hl[2], ll[2]; /* [1]: chosen where the mask is 0xff, [0]: where it is 0x00 */
+    uint32_t za[2], sb[2]; /* [1]: chosen where the mask is 0xff, [0]: where it is 0x00 */
+    uint32_t oc[2], hi[2]; /* the two entries differ for the min-sum decoders only */
 };
 /* c: magnitude bytes (0..7); flip: byte mask, 0xff where mask polarity is inverted (row parity F) */
 /* `bias`: what the caller's tb carries on top of t + 128 per byte (FAID keeps the v_perm selector's 0 / 2 / 4 / 6 in it, see
- * pass 1): folded into the three constants that meet tb */
+ * pass 1): folded into the constant that meets tb */
 template <bool MINSUM, bool FLIP = true>
 SW_FN SwUpd sw_update_consts(uint32_t c, uint32_t flip, uint32_t bias)
 {
-    const uint32_t oc_p = 0x20202020u + bias - c, oc_n = (MINSUM ? 0x20202020u + c : 0x20202020u) + bias; /* over  <=> t > hi' : tb - (hi' + 1) >= 128 */
-    const uint32_t qc_p = 0x1f1f1f1fu - bias, qc_n = 0x1f1f1f1fu - bias - c;              /* under <=> t < lo' : tb - lo' < 128        */
-    const uint32_t lc_p = 0x08080808u + bias - c, lc_n = 0x08080808u + bias + c;          /* Eb' = tb - (8 - L)                        */
-    const uint32_t hl_p = 0x97979797u, hl_n = MINSUM ? 0x97979797u : 0x97979797u - c;     /* hi' + L + 120                             */
-    const uint32_t ll_p = 0x59595959u + c, ll_n = 0x59595959u;                            /* lo' + L + 120                             */
+    const uint32_t za_p = 0x1f1f1f1fu - bias, za_n = za_p - c;                  /* zb = tb + za = t + 159 - (L < 0 ? c : 0)   */
+    const uint32_t sb_p = 0x27272727u - c, sb_n = 0x27272727u;                  /* En' + 120 = clamped zb - sb                */
+    const uint32_t oc_p = 0x3f3f3f3fu - c, oc_n = MINSUM ? 0x3f3f3f3fu : oc_p;  /* over <=> z > hi <=> zb - oc >= 128         */
+    const uint32_t hi_p = 0xbebebebeu - c, hi_n = MINSUM ? 0xbebebebeu : hi_p;  /* hi + 159                                   */
     SwUpd u;
     if (!FLIP) { /* the caller's mask already is "new message not negative" */
-        u.oc[1] = oc_p; u.oc[0] = oc_n; u.qc[1] = qc_p; u.qc[0] = qc_n; u.lc[1] = lc_p; u.lc[0] = lc_n;
-        u.hl[1] = hl_p; u.hl[0] = hl_n; u.ll[1] = ll_p; u.ll[0] = ll_n;
+        u.za[1] = za_p; u.za[0] = za_n; u.sb[1] = sb_p; u.sb[0] = sb_n; u.oc[1] = oc_p; u.oc[0] = oc_n; u.hi[1] = hi_p; u.hi[0] = hi_n;
         return u;
     }
-    u.oc[1] = sw_bitop3<SW_TT_SEL>(flip, oc_n, oc_p); u.oc[0] = sw_bitop3<SW_TT_SEL>(flip, oc_p, oc_n);
-    u.qc[1] = sw_bitop3<SW_TT_SEL>(flip, qc_n, qc_p); u.qc[0] = sw_bitop3<SW_TT_SEL>(flip, qc_p, qc_n);
-    u.lc[1] = sw_bitop3<SW_TT_SEL>(flip, lc_n, lc_p); u.lc[0] = sw_bitop3<SW_TT_SEL>(flip, lc_p, lc_n);
-    u.hl[1] = sw_bitop3<SW_TT_SEL>(flip, hl_n, hl_p); u.hl[0] = sw_bitop3<SW_TT_SEL>(flip, hl_p, hl_n);
-    u.ll[1] = sw_bitop3<SW_TT_SEL>(flip, ll_n, ll_p); u.ll[0] = sw_bitop3<SW_TT_SEL>(flip, ll_p, ll_n);
+    u.za[1] = sw_bitop3<SW_TT_SEL>(flip, za_n, za_p); u.za[0] = sw_bitop3<SW_TT_SEL>(flip, za_p, za_n);
+    u.sb[1] = sw_bitop3<SW_TT_SEL>(flip, sb_n, sb_p); u.sb[0] = sw_bitop3<SW_TT_SEL>(flip, sb_p, sb_n);
+    if (MINSUM) {
+        u.oc[1] = sw_bitop3<SW_TT_SEL>(flip, oc_n, oc_p); u.oc[0] = sw_bitop3<SW_TT_SEL>(flip, oc_p, oc_n);
+        u.hi[1] = sw_bitop3<SW_TT_SEL>(flip, hi_n, hi_p); u.hi[0] = sw_bitop3<SW_TT_SEL>(flip, hi_p, hi_n);
+    } else {
+        u.oc[1] = u.oc[0] = oc_p; u.hi[1] = u.hi[0] = hi_p;
+    }
     return u;
 }
-/* tb: t + 128 per byte; ms: 0xff where bit 7 of the (back-tracked) sign word is set, i.e. the V2C is not negative */
-SW_FN uint32_t sw_update(uint32_t tb, uint32_t ms, const SwUpd& u, uint32_t sel_sign)
+/* tb: t + 128 (+ bias) per byte; ms: byte mask picking entry [1] of the constants; c80: 0x80808080 in a register */
+template <bool MINSUM>
+SW_FN uint32_t sw_update(uint32_t tb, uint32_t ms, const SwUpd& u, uint32_t sel_sign, uint32_t c80)
 {
-    const uint32_t oc = sw_bitop3<SW_TT_SEL>(ms, u.oc[1], u.oc[0]);
-    const uint32_t qc = sw_bitop3<SW_TT_SEL>(ms, u.qc[1], u.qc[0]);
-    const uint32_t lc = sw_bitop3<SW_TT_SEL>(ms, u.lc[1], u.lc[0]);
-    const uint32_t hl = sw_bitop3<SW_TT_SEL>(ms, u.hl[1], u.hl[0]);
-    const uint32_t ll = sw_bitop3<SW_TT_SEL>(ms, u.ll[1], u.ll[0]);
-    const uint32_t mo = sw_mask7(tb - oc, sel_sign); /* over  */
-    const uint32_t mq = sw_mask7(tb + qc, sel_sign); /* not under */
-    return sw_bitop3<SW_TT_SEL>(mo, hl, sw_bitop3<SW_TT_SEL>(mq, tb - lc, ll));
+    const uint32_t za = sw_bitop3<SW_TT_SEL>(ms, u.za[1], u.za[0]);
+    const uint32_t sb = sw_bitop3<SW_TT_SEL>(ms, u.sb[1], u.sb[0]);
+    const uint32_t oc = MINSUM ? sw_bitop3<SW_TT_SEL>(ms, u.oc[1], u.oc[0]) : u.oc[1];
+    const uint32_t hi = MINSUM ? sw_bitop3<SW_TT_SEL>(ms, u.hi[1], u.hi[0]) : u.hi[1];
+    const uint32_t zb = tb + za;
+    const uint32_t mo = sw_mask7(zb - oc, sel_sign); /* over      */
+    const uint32_t mq = sw_mask7(zb, sel_sign);      /* not under */
+    return sw_bitop3<SW_TT_SEL>(mo, hi, sw_bitop3<SW_TT_SEL>(mq, zb, c80)) - sb;
 }
 
 /* ERA helpers.  Plane bit of the variable node at LDS byte address a (interleaved image: block column in the high bits,
@@ -254,13 +279,13 @@ SW_FN uint32_t sw_plane_bit(const SwLds& lds, uint32_t era_plane, uint32_t a)
 }
 
 /* ---- one layer -----------------------------------------------------------------------------------------------------
- * Tab: tab.s4(j) = 4 * shift and tab.cb256(j) = block column * 256 of edge j (uniform), tab.sb_dyn(idx) = block column * 256 +
- * shift for a per-lane edge index.
+ * Tab: tab.s4(j) = 4 * shift and tab.cb256(j) = block column * 256 of edge j (uniform), tab.sb_dyn4(4 * idx) =
+ * (block column * 256) << 16 | 4 * shift for a per-lane edge index.
  * rowpar: byte mask, 0xff in byte k if the syndrome bit of row i + 64 k is set (only read by the OMS selective offset
  * and the 2B1C error-floor tables); lme: unsat < floor_err_count for this codeword.
  * DecodeMethod 0 (NMS) is not built here: its minima run over |t| up to 31, more levels than the 8-entry thermometer holds. */
 template <int METHOD, int DEG, bool ERA = false, class Tab>
-SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, uint32_t lane, int deg, SwRow cur, bool fresh,
+SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, const SwK& K, uint32_t lane, int deg, SwRow cur, bool fresh,
                           uint32_t rowpar, bool lme, uint32_t era_edges = 0u, uint32_t era_plane = 0u)
 {
     /* ERA (EF_ELIMINATION 2, CDecoder_FAID.cpp:673-680; the caller instantiates it only inside the error-floor window of a
@@ -271,9 +296,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     static_assert(!ERA || METHOD == 2, "the erasure exists in Decode_FAID only");
     constexpr int NJ = DEG > 0 ? DEG : SW_MAX_DEG;
     constexpr bool MINSUM = SW_MINSUM(METHOD);
-    const uint32_t c01 = sw_vconst(0x01010101u), c80 = sw_vconst(0x80808080u), c7f = sw_vconst(0x7f7f7f7fu);
-    const uint32_t c78 = sw_vconst(0x78787878u), c0642 = sw_vconst(0x06040200u), cfc = sw_vconst(0xfcu);
-    const uint32_t sel_sign = sw_vconst(SW_SEL_SIGN);
+    const uint32_t c01 = K.cbit[0], c80 = K.cbit[7], c7f = K.c7f, c78 = K.c78, c0642 = K.c0642, cfc = K.cfc, sel_sign = K.sel_sign;
     const uint32_t tid4 = lane << 2;
     /* the layer's circulants first (scalar loads share the LDS counter: in flight together with LDS reads they force full drains) */
     uint32_t s4j[NJ], cbj[NJ];
@@ -287,8 +310,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
      * tb - selector = t + 128 - b is the back-tracked sign word in ONE subtraction; pass 2 compensates in its constants */
     const uint32_t bias = MINSUM ? 0u : 0x06040200u;
     const uint32_t kt_lo = sw_perm(kn, kp, 0x05010400u) + (MINSUM ? 0u : 0x02020000u), kt_hi = sw_perm(kn, kp, 0x07030602u) + (MINSUM ? 0u : 0x06060404u);
-    /* thermometer code of min(|t|, 7); entry 7 equals what v_perm returns for a saturated selector */
-    const uint32_t tt_lo = sw_vconst(0x07030100u), tt_hi = sw_vconst(0xff3f1f0fu);
+    const uint32_t tt_lo = K.tt_lo, tt_hi = K.tt_hi; /* thermometer code of min(|t|, 7) */
 
     /* ---- the old arg-min edge carries c1, not c2: move its En by the difference so that "every edge carries c2" holds ---- */
     uint32_t padd = 0, psub = 0; /* what the patch below adds to / takes from the old arg-min nodes' LDS bytes */
@@ -372,7 +394,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
             if (j & 1) sx = sw_bitop3<SW_TT_XOR3>(sx, ts[j - 1], ts[j]); else if (j == (DEG > 0 ? DEG : deg) - 1) sx ^= ts[j];
             t2 = sw_bitop3<SW_TT_A_AND_BORC>(t2, t1, u_[g]);      /* VECTOR_MIN_2 with the old min1 */
             t1 &= u_[g];
-            _Pragma("unroll") for (int b = 0; b < 5; ++b) if (!((j >> b) & 1)) ta[b] &= u_[g];)
+            _Pragma("unroll") for (int b = 0; b < 5; ++b) if (((j >> b) & 1) == (b >= 3 ? 1 : 0)) ta[b] &= u_[g];)
     }
 
     /* ---- the row's new magnitudes ---- */
@@ -402,28 +424,38 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
      * F = bit 7 of the XOR of all ts */
     const uint32_t fm = sw_mask7(sx, sel_sign);
 
-    /* ---- binary index of an edge that attains the minimum: bit b is 1 iff no edge with bit b clear attains it ---- */
+    /* ---- binary index of an edge that attains the minimum.  Bits 0..2: ta[b] runs over the edges whose index has bit b clear,
+     * the bit is 1 iff none of them attains it.  Bits 3 and 4 the other way round (fewer edges have them set): ta[3] runs over
+     * edges 8..15, ta[4] over edges 16..23, the bit is 1 iff one of them attains it; bit 3 gives way to bit 4.  With a unique
+     * minimum that is its index; a tie leaves 16 / 8 / 0 + the AND of the tied indices' low bits, not above one of the tied
+     * edges in that range, so still an edge of the row - and in a tie c1 == c2 ---- */
     uint32_t idx = 0;
 #pragma unroll
-    for (int b = 0; b < 5; ++b) {
+    for (int b = 4; b >= 0; --b) {
         const uint32_t dd = sw_bitop3<SW_TT_XORAND>(ta[b], t1, c7f);
-        idx = sw_bitop3<SW_TT_ANDNOT_OR>(idx, (dd + c7f) >> (7 - b), 0x01010101u << b); /* bit 7 of every byte of dd + 0x7f: dd != 0 */
+        const uint32_t ne = (dd + c7f) >> (7 - b); /* bit b of every byte: ta[b] != t1 */
+        /* (a row of the generic instance with no edge in 16..23 / 8..15 leaves that accumulator untouched: bit stays 0) */
+        if (b == 4) idx = (DEG == 0 && deg <= 16) ? 0u : ~ne & (0x01010101u << 4);
+        else if (b == 3) idx = (DEG == 0 && deg <= 8) ? idx : sw_bitop3<0xf2>(idx, ne | (idx >> 1), 0x01010101u << 3); /* a | (~b & c) */
+        else idx = sw_bitop3<SW_TT_ANDNOT_OR>(idx, ne, 0x01010101u << b);
     }
-    /* a tie leaves the AND of the tied indices: still an edge of the row, and in a tie c1 == c2 */
 
     /* ---- the new arg-min edge: address, exact V2C, exact new En (its En in LDS is still the old value) ---- */
     uint32_t pa[4], sbk[4], gb = 0, xb = 0;
+    const uint32_t idx4 = idx << 2;
 #pragma unroll
 #ifdef SW_EXP_NO_ARGMIN /* timing experiment only: results are wrong */
-    for (int k = 0; k < 4; ++k) sbk[k] = cbj[k] | (s4j[k] >> 2);
+    for (int k = 0; k < 4; ++k) sbk[k] = (cbj[k] << 16) | s4j[k];
 #else
-    for (int k = 0; k < 4; ++k) sbk[k] = tab.sb_dyn((idx >> (8 * k)) & 31u);
+    for (int k = 0; k < 4; ++k) sbk[k] = tab.sb_dyn4((idx4 >> (8 * k)) & 0x7cu);
 #endif
     SW_SCHED_FENCE();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t x4 = tid4 + ((sbk[k] & 255u) << 2);
-        pa[k] = ((x4 & 0xfcu) | (sbk[k] & ~255u)) + (((x4 >> 8) + (uint32_t)k) & 3u);
+        const uint32_t x = tid4 + sbk[k]; /* low half: 4 * (lane + shift) < 2048, high half: block column * 256 */
+        const uint32_t a = (x & 0xfcu) | (x >> 16);
+        const uint32_t q = (x >> 8) & 3u;
+        pa[k] = k ? a | ((q + (uint32_t)k) & 3u) : a | q;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -435,7 +467,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     }
     /* the arg-min edges as one-hot bits inside their 8-edge word (byte k: 1 << (index mod 8)) and the word they are in
      * (index div 8 = 0, 1, 2) as byte masks, all four rows at once */
-    const uint32_t oh8 = sw_perm(sw_vconst(0x80402010u), sw_vconst(0x08040201u), idx & 0x07070707u);
+    const uint32_t oh8 = sw_perm(K.oh_hi, K.oh_lo, idx & 0x07070707u);
     const uint32_t in1 = sw_mask7(idx << 4, sel_sign), in2 = sw_mask7(idx << 3, sel_sign); /* index bit 3 / bit 4 */
     {   /* old message on that edge negative: bit (index mod 8) of byte k of sign word (index div 8) */
         const uint32_t w = sw_bitop3<SW_TT_SEL>(in2, cur.x[2], sw_bitop3<SW_TT_SEL>(in1, cur.x[1], cur.x[0]));
@@ -461,29 +493,28 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, u
     const uint32_t negA = ~(msA ^ fm); /* byte mask: the new message on the arg-min edge is negative */
     /* used once: flip = 0 leaves [1] = "not negative" constants, [0] = "negative" ones, picked by the combined mask */
     const SwUpd u1 = sw_update_consts<MINSUM, false>(c1n, 0u, bias);
-    const uint32_t enA = sw_update(tbA, ~negA, u1, sel_sign);
+    const uint32_t enA = sw_update<MINSUM>(tbA, ~negA, u1, sel_sign, c80);
 
     /* ---- pass 2 (CDecoder_FAID.cpp:909-929, CDecoder_OMS.cpp:452-471): every edge as if it carried c2 ---- */
     const SwUpd u2 = sw_update_consts<MINSUM>(c2n, fm, bias);
     uint32_t ns[3] = { 0u, 0u, 0u };
     uint32_t cbit[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) cbit[e] = sw_vconst(0x01010101u << e);
+    for (int e = 0; e < 8; ++e) cbit[e] = K.cbit[e];
 #pragma unroll
     for (int j0 = 0; j0 < NJ; j0 += SW_ILP) { /* stage by stage over groups of edges, as in pass 1 */
-        uint32_t oc[SW_ILP], qc[SW_ILP], lc[SW_ILP], hl[SW_ILP], ll[SW_ILP], en[SW_ILP];
-        SW_EDGES(oc[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.oc[1], u2.oc[0]);)
-        SW_EDGES(qc[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.qc[1], u2.qc[0]);)
-        SW_EDGES(lc[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.lc[1], u2.lc[0]);)
-        SW_EDGES(hl[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.hl[1], u2.hl[0]);)
-        SW_EDGES(ll[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.ll[1], u2.ll[0]);)
-        SW_EDGES(oc[g] = tb[j] - oc[g];)
-        SW_EDGES(qc[g] = tb[j] + qc[g];)
-        SW_EDGES(lc[g] = tb[j] - lc[g];)
-        SW_EDGES(oc[g] = sw_mask7(oc[g], sel_sign);)   /* over      */
-        SW_EDGES(qc[g] = sw_mask7(qc[g], sel_sign);)   /* not under */
-        SW_EDGES(en[g] = sw_bitop3<SW_TT_SEL>(qc[g], lc[g], ll[g]);)
-        SW_EDGES(en[g] = sw_bitop3<SW_TT_SEL>(oc[g], hl[g], en[g]);)
+        uint32_t za[SW_ILP], sb[SW_ILP], oc[SW_ILP], hi[SW_ILP], mo[SW_ILP], mq[SW_ILP], en[SW_ILP];
+        SW_EDGES(za[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.za[1], u2.za[0]);)
+        SW_EDGES(sb[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.sb[1], u2.sb[0]);)
+        SW_EDGES(oc[g] = MINSUM ? sw_bitop3<SW_TT_SEL>(ms[j], u2.oc[1], u2.oc[0]) : u2.oc[1];)
+        SW_EDGES(hi[g] = MINSUM ? sw_bitop3<SW_TT_SEL>(ms[j], u2.hi[1], u2.hi[0]) : u2.hi[1];)
+        SW_EDGES(za[g] = tb[j] + za[g];)                 /* zb */
+        SW_EDGES(oc[g] = za[g] - oc[g];)
+        SW_EDGES(mo[g] = sw_mask7(oc[g], sel_sign);)     /* over      */
+        SW_EDGES(mq[g] = sw_mask7(za[g], sel_sign);)     /* not under */
+        SW_EDGES(en[g] = sw_bitop3<SW_TT_SEL>(mq[g], za[g], c80);)
+        SW_EDGES(en[g] = sw_bitop3<SW_TT_SEL>(mo[g], hi[g], en[g]);)
+        SW_EDGES(en[g] = en[g] - sb[g];)
         SW_EDGES(en[g] = sw_alignbyte(en[g], en[g], 4u - rq[j]);)
         SW_EDGES(lds.wr32(ad[j], en[g]);)
         SW_EDGES(ns[j >> 3] = sw_bitop3<SW_TT_ANDNOT_OR>(ns[j >> 3], ms[j], cbit[j & 7]);) /* bit e of byte k: V2C on edge 8 g + e not negative */

@@ -40,7 +40,7 @@ struct TabDev {
     __device__ __forceinline__ uint32_t sb(int j) const { return __builtin_amdgcn_readfirstlane(row[j]); }
     __device__ __forceinline__ uint32_t s4(int j) const { return (sb(j) & 255u) << 2; }
     __device__ __forceinline__ uint32_t cb256(int j) const { return sb(j) & ~255u; }
-    __device__ __forceinline__ uint32_t sb_dyn(uint32_t idx) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)sbv); }
+    __device__ __forceinline__ uint32_t sb_dyn4(uint32_t idx4) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)idx4, (int)sbv); }
 };
 
 /* one wave per codeword: n_iter layered iterations of DecodeMethod 2 (no syndrome needed) on an interleaved, biased En image */
@@ -54,16 +54,17 @@ __global__ __launch_bounds__(64) void k_layers(int n_var, int nbr, const int* de
     for (int i = lane; i < n_var / 4; i += 64) s32[i] = g32[i];
     __syncthreads();
     SwLds lds = SwLds();
+    const SwK K = sw_consts();
     SwRow* r = rows + (size_t)cw * nbr * 64;
     for (int it = 1; it <= n_iter; ++it) {
         const SwParams p = p6[it <= 5 ? it - 1 : 5];
         for (int br = 0; br < nbr; ++br) {
-            TabDev tab; tab.row = sb + br * 24; tab.sbv = sb[br * 24 + (lane % 24)];
+            TabDev tab; tab.row = sb + br * 24; { const uint32_t v = sb[br * 24 + (lane % 24)]; tab.sbv = ((v & ~255u) << 16) | ((v & 255u) << 2); }
             SwRow cur = { { 0u, 0u, 0u }, 0u, { 0u, 0u } };
             if (it > 1) cur = r[br * 64 + lane];
             SwRow st;
-            if (deg[br] == 23) st = sw_layer_step<2, 23>(lds, tab, p, (uint32_t)lane, 23, cur, it == 1, 0u, false);
-            else st = sw_layer_step<2, 0>(lds, tab, p, (uint32_t)lane, deg[br], cur, it == 1, 0u, false);
+            if (deg[br] == 23) st = sw_layer_step<2, 23>(lds, tab, p, K, (uint32_t)lane, 23, cur, it == 1, 0u, false);
+            else st = sw_layer_step<2, 0>(lds, tab, p, K, (uint32_t)lane, deg[br], cur, it == 1, 0u, false);
             r[br * 64 + lane] = st;
             __syncthreads();
         }

@@ -19,19 +19,20 @@ struct HostTab {
     uint32_t sb(int j) const { return row[j]; }
     uint32_t s4(int j) const { return (row[j] & 255u) << 2; }
     uint32_t cb256(int j) const { return row[j] & ~255u; }
-    uint32_t sb_dyn(uint32_t j) const { return row[j]; }
+    uint32_t sb_dyn4(uint32_t j4) const { const uint32_t v = row[j4 >> 2]; return ((v & ~255u) << 16) | ((v & 255u) << 2); }
 };
 
 template <int METHOD>
 SwRow step(int deg, bool spec, const SwLds& lds, const HostTab& tab, const SwParams& p, uint32_t lane, SwRow cur, bool fresh,
            uint32_t rowpar, bool lme, bool erase = false, uint32_t era_edges = 0, uint32_t era_plane = 0)
 {
+    const SwK K = sw_consts();
     if (erase) {
-        if constexpr (METHOD == 2) return sw_layer_step<METHOD, 0, true>(lds, tab, p, lane, deg, cur, fresh, rowpar, lme, era_edges, era_plane);
+        if constexpr (METHOD == 2) return sw_layer_step<METHOD, 0, true>(lds, tab, p, K, lane, deg, cur, fresh, rowpar, lme, era_edges, era_plane);
     }
-    if (spec && deg == 23) return sw_layer_step<METHOD, 23>(lds, tab, p, lane, deg, cur, fresh, rowpar, lme);
-    if (spec && deg == 22) return sw_layer_step<METHOD, 22>(lds, tab, p, lane, deg, cur, fresh, rowpar, lme);
-    return sw_layer_step<METHOD, 0>(lds, tab, p, lane, deg, cur, fresh, rowpar, lme);
+    if (spec && deg == 23) return sw_layer_step<METHOD, 23>(lds, tab, p, K, lane, deg, cur, fresh, rowpar, lme);
+    if (spec && deg == 22) return sw_layer_step<METHOD, 22>(lds, tab, p, K, lane, deg, cur, fresh, rowpar, lme);
+    return sw_layer_step<METHOD, 0>(lds, tab, p, K, lane, deg, cur, fresh, rowpar, lme);
 }
 }
 
