@@ -521,8 +521,8 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
     }
 #undef SW_EDGES
     /* the arg-min edge carries c1: its exact En replaces the as-if value pass 2 wrote (same lane, LDS operations in order) */
-#pragma unroll
 #ifndef SW_EXP_NO_ARGMIN
+#pragma unroll
     for (int k = 0; k < 4; ++k) lds.wr8(pa[k], enA >> (8 * k));
 #endif
 
