@@ -67,17 +67,25 @@ __device__ int syndrome(CCode c, const LfDevCode* gc, uint32_t* sP, int tid, uin
     typedef const __attribute__((address_space(3))) uint32_t lds_u32;
     const int nbr = c->nbr;
     int cnt = 0;
-    for (int task = tid; task < nbr * 8; task += T) {
-        const uint2* tab = &gc->synw[task >> 3][0][task & 7];
+    /* T = 64: 96 tasks would leave half the wave idle in a second round, so every task is cut in two halves of the circulant
+     * list held by neighbouring lanes (192 half tasks = three full rounds of 12 circulants instead of two rounds of 24) */
+    constexpr int PARTS = T == 64 ? 2 : 1, JP = LF_MAX_DEG / PARTS;
+    static_assert(LF_MAX_DEG % PARTS == 0, "circulant slots must split evenly");
+    for (int ht = tid; ht < nbr * 8 * PARTS; ht += T) {
+        const int task = ht / PARTS, part = ht % PARTS;
+        const uint2* tab = &gc->synw[task >> 3][part * JP][task & 7];
         uint32_t acc = 0;
 #pragma unroll
-        for (int j = 0; j < LF_MAX_DEG; ++j) {
+        for (int j = 0; j < JP; ++j) {
             const uint2 e = tab[j * 8];
             const uint32_t w0 = *(lds_u32*)(size_t)(e.x & 0xffffu), w1 = *(lds_u32*)(size_t)(e.x >> 16);
             acc ^= __builtin_amdgcn_alignbit(w1, w0, e.y);
         }
-        sP[task] = acc;
-        cnt += __popc(acc);
+        if (PARTS == 2) acc ^= (uint32_t)__builtin_amdgcn_mov_dpp((int)acc, 0xb1, 0xf, 0xf, false); /* quad_perm [1,0,3,2]: the other half */
+        if (part == 0) {
+            sP[task] = acc;
+            cnt += __popc(acc);
+        }
     }
     cnt = add_reduce32(cnt);
     const int wave_cnt = __builtin_amdgcn_readlane(cnt, 31) + __builtin_amdgcn_readlane(cnt, 63);
