@@ -341,57 +341,75 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
     }
 
     const SwK swk = sw_consts();
-    {
-        for (;;) {
-            if (prog >= t_end) break; /* loops exhausted (also OMS after max_iter iterations) */
-            if (max_bf > 0 && prog >= t_bf0 && !in_bf) {
-                /* the layered loop ran out: enter the bit-flipping stage (CDecoder_FAID.cpp:6411-6428) */
-                uint32_t conf[LF_MAX_BC * 8 / LF_T4]; /* this lane's share of the 2B1C confidence plane */
-                if (METHOD == 5) {
-                    build_plane4<true>(c, sHard, f->hard2_thr, tid); /* staged where the hard plane will go */
-#pragma unroll
-                    for (int k = 0; k < LF_MAX_BC * 8 / LF_T4; ++k) conf[k] = (tid + k * LF_T4 < nw) ? sHard[tid + k * LF_T4] : 0u;
-                    __syncthreads();
-                }
+    bool parked = false;
+    uint32_t pA = 0, pB = 0;
+    /* ---- layered iterations (the syndrome stage in front of iteration prog is decision point prog) ---- */
+    if (!in_bf) {
+        while (prog < t_end && !(max_bf > 0 && prog >= t_bf0)) {
+            bool lme = false, have_par = false;
+            /* l_checksum_ and the unsatisfied count are consumed only inside the error-floor window
+             * (nombre_iterations <= floor_iter_thresh: OMS selective offset CDecoder_OMS.cpp:388, 2B1C tables
+             * CDecoder_FAID.cpp:714) and never by DecodeMethod 2; elsewhere only unsat != 0 matters */
+            const bool needs_checksums = max_iter - prog <= f->floor_iter_thresh; /* never for the shipped DecodeMethod 2: -1 */
+            if (needs_checksums || !layer0_dirty4(c, tid)) {
                 build_plane4<false>(c, sHard, 0, tid);
-                /* En is dead from here on: its bytes take hard_ch (= hard) and hard2 */
-                for (int i = tid; i < nw; i += LF_T4) sHard0[i] = sHard[i];
-                if (METHOD == 5) {
+                const int unsat = syndrome<LF_T4, false>(c, a.code, sP, tid, pA, pB, sRed);
+                /* clean on the group's front: park, unless a group mate is known to have passed this point */
+                if (unsat == 0 && prog >= kmax && !group_passed(a.live, g, prog, tid)) { parked = true; break; }
+                if (LF4_OMS(METHOD)) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
+                else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
+                have_par = true;
+            }
+            publish_pass(a.live, cw, prog, tid);
+            if (METHOD == 2 && f->ef == 2 && needs_checksums && have_par && lme) {
+                /* EF_ELIMINATION 2 inside the window, few unsatisfied checks: this iteration erases (CDecoder_FAID.cpp:673-680) */
+                build_erasure_plane4(c, a.code, sHard, sP, f->W, tid);
+                main_step4<METHOD, METHOD == 2>(c, f, a.code, swk, g_rows, tid, prog, sP, true, lme, lf_lds_off_hard(N));
+            } else {
+                main_step4<METHOD, false>(c, f, a.code, swk, g_rows, tid, prog, sP, have_par && needs_checksums, lme, 0u);
+            }
+            prog++;
+        }
+        if (!parked && prog < t_end) {
+            /* the layered loop ran out: enter the bit-flipping stage (CDecoder_FAID.cpp:6411-6428) */
+            uint32_t conf[LF_MAX_BC * 8 / LF_T4]; /* this lane's share of the 2B1C confidence plane */
+            if (METHOD == 5) {
+                build_plane4<true>(c, sHard, f->hard2_thr, tid); /* staged where the hard plane will go */
 #pragma unroll
-                    for (int k = 0; k < LF_MAX_BC * 8 / LF_T4; ++k) if (tid + k * LF_T4 < nw) sHard2[tid + k * LF_T4] = conf[k];
-                }
-                ls.Th = (int8_t)f->W; ls.l0 = 0; ls.l1 = 0; ls.t = 1;
-                in_bf = true;
+                for (int k = 0; k < LF_MAX_BC * 8 / LF_T4; ++k) conf[k] = (tid + k * LF_T4 < nw) ? sHard[tid + k * LF_T4] : 0u;
                 __syncthreads();
             }
-            uint32_t pA = 0, pB = 0;
-            if (!in_bf) {
-                bool lme = false, have_par = false;
-                /* l_checksum_ and the unsatisfied count are consumed only inside the error-floor window
-                 * (nombre_iterations <= floor_iter_thresh: OMS selective offset CDecoder_OMS.cpp:388, 2B1C tables
-                 * CDecoder_FAID.cpp:714) and never by DecodeMethod 2; elsewhere only unsat != 0 matters */
-                const bool needs_checksums = max_iter - prog <= f->floor_iter_thresh; /* never for the shipped DecodeMethod 2: -1 */
-                if (needs_checksums || !layer0_dirty4(c, tid)) {
-                    build_plane4<false>(c, sHard, 0, tid);
-                    const int unsat = syndrome<LF_T4, false>(c, a.code, sP, tid, pA, pB, sRed);
-                    /* clean on the group's front: park, unless a group mate is known to have passed this point */
-                    if (unsat == 0 && prog >= kmax && !group_passed(a.live, g, prog, tid)) break;
-                    if (LF4_OMS(METHOD)) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
-                    else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
-                    have_par = true;
-                }
+            build_plane4<false>(c, sHard, 0, tid);
+            /* En is dead from here on: its bytes take hard_ch (= hard) and hard2 */
+            for (int i = tid; i < nw; i += LF_T4) sHard0[i] = sHard[i];
+            if (METHOD == 5) {
+#pragma unroll
+                for (int k = 0; k < LF_MAX_BC * 8 / LF_T4; ++k) if (tid + k * LF_T4 < nw) sHard2[tid + k * LF_T4] = conf[k];
+            }
+            ls.Th = (int8_t)f->W; ls.l0 = 0; ls.l1 = 0; ls.t = 1;
+            in_bf = true;
+            __syncthreads();
+        }
+    }
+    /* ---- bit-flipping iterations.  Nothing of the layer step is alive here, so the lanes keep their entries of the walk
+     * tables in registers for the whole stage (no table load, hence no exposed memory latency, per iteration) ---- */
+    if (in_bf && !parked) {
+        if (METHOD != 3 && syn_cache_fits(c->nbr) && bf_cache_fits(c, f)) {
+            SynCache sc;
+            BfCache bc;
+            syn_cache_load(a.code, c->nbr, tid, sc);
+            bf_cache_load(c, a.code, tid, bc);
+            while (prog < t_end) {
+                const int unsat = syndrome<LF_T4, false, true>(c, a.code, sP, tid, pA, pB, sRed, &sc);
+                if (unsat == 0 && prog >= kmax && !group_passed(a.live, g, prog, tid)) { parked = true; break; }
                 publish_pass(a.live, cw, prog, tid);
-                if (METHOD == 2 && f->ef == 2 && needs_checksums && have_par && lme) {
-                    /* EF_ELIMINATION 2 inside the window, few unsatisfied checks: this iteration erases (CDecoder_FAID.cpp:673-680) */
-                    build_erasure_plane4(c, a.code, sHard, sP, f->W, tid);
-                    main_step4<METHOD, METHOD == 2>(c, f, a.code, swk, g_rows, tid, prog, sP, true, lme, lf_lds_off_hard(N));
-                } else {
-                    main_step4<METHOD, false>(c, f, a.code, swk, g_rows, tid, prog, sP, have_par && needs_checksums, lme, 0u);
-                }
+                bf_step<LF_T4, METHOD, true>(c, f, a.code, sHard, sHard0, sHard2, sP, tid, ls, sRed, &bc);
                 prog++;
-            } else {
+            }
+        } else {
+            while (prog < t_end) {
                 const int unsat = syndrome<LF_T4, false>(c, a.code, sP, tid, pA, pB, sRed);
-                if (unsat == 0 && prog >= kmax && !group_passed(a.live, g, prog, tid)) break;
+                if (unsat == 0 && prog >= kmax && !group_passed(a.live, g, prog, tid)) { parked = true; break; }
                 publish_pass(a.live, cw, prog, tid);
                 if (METHOD == 3) bf_step_plain<LF_T4>(c, f, a.code, sHard, sHard2 + nw /* 4 count planes in the dead En */, sP, tid, sRed);
                 else bf_step<LF_T4, METHOD>(c, f, a.code, sHard, sHard0, sHard2, sP, tid, ls, sRed);

@@ -61,12 +61,55 @@ __device__ __forceinline__ int add_reduce32(int v)
  * + one v_xor per circulant and no cross-lane reduction; slots beyond the row degree point at a zero word.
  * Writes the parity plane sP (bit r = l_checksum_[r]), returns the number of unsatisfied checks; with ROWBITS pA / pB
  * get bit br = parity of this thread's rows tid / tid + 128 in layer br (the error-floor tables need them). */
-template <int T, bool ROWBITS>
-__device__ int syndrome(CCode c, const LfDevCode* gc, uint32_t* sP, int tid, uint32_t& pA, uint32_t& pB, int* sRed)
+/* The bit-flipping stage runs the same walk up to _maxBFiter times with nothing else alive in the registers (the layer step's
+ * state is dead), and with two waves per SIMD nothing hides the latency of the table loads: the one-wave kernel keeps its
+ * lanes' table entries in registers for the whole stage (codes of up to LF_SYN_ROUNDS * 32 / 8 layers). */
+#define LF_SYN_ROUNDS 3
+#define LF_SYN_JP (LF_MAX_DEG / 2)
+struct SynCache {
+    uint2 e[LF_SYN_ROUNDS][LF_SYN_JP];
+};
+__device__ __forceinline__ bool syn_cache_fits(int nbr) { return nbr * 16 <= LF_SYN_ROUNDS * 64; }
+__device__ __forceinline__ void syn_cache_load(const LfDevCode* gc, int nbr, int tid, SynCache& sc)
+{
+#pragma unroll
+    for (int r = 0; r < LF_SYN_ROUNDS; ++r) {
+        const int ht = tid + 64 * r;
+        const int task = ht < nbr * 16 ? ht >> 1 : 0, part = ht & 1;
+#pragma unroll
+        for (int j = 0; j < LF_SYN_JP; ++j) sc.e[r][j] = gc->synw[task >> 3][part * LF_SYN_JP + j][task & 7];
+    }
+}
+
+template <int T, bool ROWBITS, bool CACHED = false>
+__device__ int syndrome(CCode c, const LfDevCode* gc, uint32_t* sP, int tid, uint32_t& pA, uint32_t& pB, int* sRed,
+                        const SynCache* sc = nullptr)
 {
     typedef const __attribute__((address_space(3))) uint32_t lds_u32;
     const int nbr = c->nbr;
     int cnt = 0;
+    if (CACHED) {
+        static_assert(!CACHED || T == 64, "register tables: one-wave kernel only");
+#pragma unroll
+        for (int r = 0; r < LF_SYN_ROUNDS; ++r) {
+            const int ht = tid + 64 * r;
+            if (ht < nbr * 16) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int j = 0; j < LF_SYN_JP; ++j) {
+                    const uint2 e = sc->e[r][j];
+                    const uint32_t w0 = *(lds_u32*)(size_t)(e.x & 0xffffu), w1 = *(lds_u32*)(size_t)(e.x >> 16);
+                    acc ^= __builtin_amdgcn_alignbit(w1, w0, e.y);
+                }
+                acc ^= (uint32_t)__builtin_amdgcn_mov_dpp((int)acc, 0xb1, 0xf, 0xf, false); /* the other half of the circulant list */
+                if (!(ht & 1)) {
+                    sP[ht >> 1] = acc;
+                    cnt += __popc(acc);
+                }
+            }
+        }
+    } else
+    {
     /* T = 64: 96 tasks would leave half the wave idle in a second round, so every task is cut in two halves of the circulant
      * list held by neighbouring lanes (192 half tasks = three full rounds of 12 circulants instead of two rounds of 24) */
     constexpr int PARTS = T == 64 ? 2 : 1, JP = LF_MAX_DEG / PARTS;
@@ -86,6 +129,7 @@ __device__ int syndrome(CCode c, const LfDevCode* gc, uint32_t* sP, int tid, uin
             sP[task] = acc;
             cnt += __popc(acc);
         }
+    }
     }
     cnt = add_reduce32(cnt);
     const int wave_cnt = __builtin_amdgcn_readlane(cnt, 31) + __builtin_amdgcn_readlane(cnt, 63);
@@ -107,9 +151,29 @@ __device__ int syndrome(CCode c, const LfDevCode* gc, uint32_t* sP, int tid, uin
  *      CDecoder_FAID_2B1C.cpp:6801-6814) --------------------------------------------------------------- */
 __device__ __forceinline__ int bit_of(const uint32_t* words, int v) { return (int)((words[v >> 5] >> (v & 31)) & 1u); }
 
-template <int T, int METHOD>
+/* register copy of this lane's units of the bit-sliced flip (one-wave kernel, see SynCache) */
+#define LF_BF_ROUNDS 4
+struct BfCache {
+    uint32_t cc[LF_BF_ROUNDS][3];
+    int w0[LF_BF_ROUNDS];
+};
+__device__ __forceinline__ bool bf_cache_fits(CCode c, CCfg f) { return f->bf_fast && c->n_wcols * 4 <= LF_BF_ROUNDS * 64; }
+__device__ __forceinline__ void bf_cache_load(CCode c, const LfDevCode* gc, int tid, BfCache& bc)
+{
+    const int units = c->n_wcols * 4;
+#pragma unroll
+    for (int r = 0; r < LF_BF_ROUNDS; ++r) {
+        const int u = tid + 64 * r;
+        const int cb = gc->wcol[u < units ? u >> 2 : 0];
+        bc.w0[r] = cb * 8 + 2 * (u & 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) bc.cc[r][k] = gc->colcirc[cb][k];
+    }
+}
+
+template <int T, int METHOD, bool CACHED = false>
 __device__ void bf_step(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, const uint32_t* sHard0, uint32_t* sHard2,
-                        const uint32_t* sP, int tid, LfLaneState& ls, int* sRed)
+                        const uint32_t* sP, int tid, LfLaneState& ls, int* sRed, const BfCache* bc = nullptr)
 {
     const int W = f->W;
     /* threshold state machine on int8 lanes (CDecoder_FAID.cpp:6787-6799) */
@@ -128,16 +192,14 @@ __device__ void bf_step(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, c
     if (f->bf_fast) {
         /* bit-sliced: one (weight-3 block column, 64-VN window) per lane */
         const int units = c->n_wcols * 4;
-        for (int u = tid; u < units; u += T) {
-            const int cb = gc->wcol[u >> 2];
+        static_assert(!CACHED || T == 64, "register tables: one-wave kernel only");
+        auto unit = [&](int u, uint32_t cc0, uint32_t cc1, uint32_t cc2, int w0) {
             const uint32_t win = (uint32_t)(u & 3);
+            const uint32_t cc[3] = { cc0, cc1, cc2 };
             uint32_t plo[3], phi[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const uint32_t cc = gc->colcirc[cb][k];
-                window64(sP + (cc & 0xffu) * 8u, (64u * win - ((cc >> 8) & 0xffu)) & 255u, plo[k], phi[k]);
-            }
-            const int w0 = cb * 8 + 2 * (int)win;
+            for (int k = 0; k < 3; ++k)
+                window64(sP + (cc[k] & 0xffu) * 8u, (64u * win - ((cc[k] >> 8) & 0xffu)) & 255u, plo[k], phi[k]);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const uint32_t p1 = h ? phi[0] : plo[0], p2 = h ? phi[1] : plo[1], p3 = h ? phi[2] : plo[2];
@@ -158,6 +220,18 @@ __device__ void bf_step(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, c
                 } else {
                     sHard[w0 + h] = hd ^ m;
                 }
+            }
+        };
+        if (CACHED) {
+#pragma unroll
+            for (int r = 0; r < LF_BF_ROUNDS; ++r) {
+                const int u = tid + 64 * r;
+                if (u < units) unit(u, bc->cc[r][0], bc->cc[r][1], bc->cc[r][2], bc->w0[r]);
+            }
+        } else {
+            for (int u = tid; u < units; u += T) {
+                const int cb = gc->wcol[u >> 2];
+                unit(u, gc->colcirc[cb][0], gc->colcirc[cb][1], gc->colcirc[cb][2], cb * 8 + 2 * (u & 3));
             }
         }
     } else {
