@@ -317,10 +317,13 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
 #ifndef SW_EXP_NO_OLDPATCH
     if (!fresh) {
         const uint32_t a0 = cur.pa[0] & 0xffffu, a1 = cur.pa[0] >> 16, a2 = cur.pa[1] & 0xffffu, a3 = cur.pa[1] >> 16;
-        const uint32_t g = lds.rd8(a0) | (lds.rd8(a1) << 8) | (lds.rd8(a2) << 16) | (lds.rd8(a3) << 24);
+        SW_SCHED_FENCE(); /* the four reads back to back: one LDS round trip, not one per read */
+        const uint32_t g0 = lds.rd8(a0), g1 = lds.rd8(a1), g2 = lds.rd8(a2), g3 = lds.rd8(a3);
         const uint32_t mneg = sw_mask7(cur.cw << 1, sel_sign); /* bit 6: the arg-min message is negative */
         /* En - L(c1) = (En - sigma (c1 - c2)) - sigma c2 */
         padd = sw_bitop3<SW_TT_SEL>(mneg, c1o, c2o); psub = sw_bitop3<SW_TT_SEL>(mneg, c2o, c1o);
+        SW_SCHED_FENCE();
+        const uint32_t g = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
         const uint32_t r = g + padd - psub;
         lds.wr8(a0, r); lds.wr8(a1, r >> 8); lds.wr8(a2, r >> 16); lds.wr8(a3, r >> 24);
     }

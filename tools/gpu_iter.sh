@@ -1,6 +1,6 @@
 # quick iteration loop on the GPU box: parity tests (fast subset first) then a short bench
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 || exit 1
+timeout -k 10 900 python -m pytest ${TESTS:-tests} -m gpu -x -q 2>&1 | tail -15 || exit 1
 timeout -k 10 600 python bench.py --steps 5 --warmup 1 --no-cpu 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
