@@ -42,6 +42,20 @@ typedef __attribute__((address_space(3))) uint32_t lds4_u32;
 __device__ __forceinline__ uint32_t lds4_rd(uint32_t a) { return *(const lds4_u32*)(size_t)a; }
 __device__ __forceinline__ void lds4_wr(uint32_t a, uint32_t v) { *(lds4_u32*)(size_t)a = v; }
 
+/* n words from global memory into LDS, B loads per lane in flight at a time: with two waves per SIMD a "load, wait, store" loop
+ * exposes one memory round trip per word */
+template <int B>
+__device__ __forceinline__ void copy_in(uint32_t* dst, const uint32_t* __restrict__ src, int n, int tid)
+{
+    for (int i0 = 0; i0 < n; i0 += B * LF_T4) {
+        uint32_t w[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) { const int i = i0 + u * LF_T4 + tid; w[u] = i < n ? src[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < B; ++u) { const int i = i0 + u * LF_T4 + tid; if (i < n) dst[i] = w[u]; }
+    }
+}
+
 /* hard decision En > 0 on the biased bytes (En + 120 >= 121): bit 7 of every byte of x + 7 */
 __device__ __forceinline__ uint32_t hard_flags(uint32_t x) { return x + 0x07070707u; }
 
@@ -317,25 +331,62 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
         const int8_t* src_i = gi + (size_t)lane_in_group * (size_t)K;
         const int8_t* src_p = gi + (size_t)LNSFAID_GROUP * (size_t)K + (size_t)lane_in_group * (size_t)M;
         const int first_erased = N - c->puncture_tail;
-        for (int cb = 0; cb < c->nbc; ++cb) {
-            uint32_t w = 0;
+        const int nbc = c->nbc;
+        if ((((size_t)a.fix_input) & 3u) == 0u) {
+            /* K, M and N are multiples of Z = 256: a block column is 64 aligned dwords of one of the two rows.  Lane d loads
+             * dword d (variable nodes 4 d .. 4 d + 3) of LF_STAGE_COLS columns at a time, all loads in flight together, and
+             * scatters the four bytes to their places in the interleaved image (node n: dword n mod 64, byte n div 64). */
+            constexpr int SB = 23;
+            const uint32_t base_d = ((16u * (uint32_t)tid) & 0xffu) + ((uint32_t)tid >> 4);
+            const SwLds lds = SwLds();
+            for (int cb0 = 0; cb0 < nbc; cb0 += SB) {
+                uint32_t w[SB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int v = cb * LF_Z + tid + 64 * k;
-                int x = v < K ? src_i[v] : src_p[v - K];
-                if (v >= first_erased) x = 0;
-                w |= (uint32_t)((x + SW_BIAS_EN) & 0xff) << (8 * k);
+                for (int u = 0; u < SB; ++u) {
+                    const int cb = cb0 + u;
+                    if (cb < nbc) { /* uniform */
+                        const int8_t* col = cb * LF_Z < K ? src_i + cb * LF_Z : src_p + (cb * LF_Z - K);
+                        w[u] = ((const uint32_t*)col)[tid];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int cb = cb0 + u;
+                    if (cb < nbc) {
+                        uint32_t x = w[u];
+                        const int lim = first_erased - cb * LF_Z; /* nodes of this column from lim on are erased */
+                        if (lim < LF_Z) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) if (4 * tid + k >= lim) x &= ~(0xffu << (8 * k));
+                        }
+                        x = ((x & 0x7f7f7f7fu) + (uint32_t)SW_BIAS_EN * 0x01010101u) ^ (x & 0x80808080u); /* + SW_BIAS_EN (< 128) per byte, no carries */
+                        const uint32_t ad = (uint32_t)cb * 256u + base_d;
+                        lds.wr8(ad, x); lds.wr8(ad + 4u, x >> 8); lds.wr8(ad + 8u, x >> 16); lds.wr8(ad + 12u, x >> 24);
+                    }
+                }
             }
-            lds4_wr((uint32_t)cb * 256u + 4u * (uint32_t)tid, w);
+        } else {
+            for (int cb = 0; cb < nbc; ++cb) { /* caller's buffer not dword aligned: byte loads */
+                uint32_t w = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int v = cb * LF_Z + tid + 64 * k;
+                    int x = v < K ? src_i[v] : src_p[v - K];
+                    if (v >= first_erased) x = 0;
+                    w |= (uint32_t)((x + SW_BIAS_EN) & 0xff) << (8 * k);
+                }
+                lds4_wr((uint32_t)cb * 256u + 4u * (uint32_t)tid, w);
+            }
         }
         __syncthreads();
         prog = 1;
     } else if (!in_bf) {
-        uint32_t* dst = (uint32_t*)smem;
-        for (int i = tid; i < (N >> 2); i += LF_T4) dst[i] = g_en[i];
+        copy_in<23>((uint32_t*)smem, g_en, N >> 2, tid);
         __syncthreads();
     } else {
-        for (int i = tid; i < nw; i += LF_T4) { sHard[i] = g_bits[i]; sHard0[i] = g_bits[nw + i]; sHard2[i] = g_bits[2 * nw + i]; }
+        copy_in<9>(sHard, g_bits, nw, tid);
+        copy_in<9>(sHard0, g_bits + nw, nw, tid);
+        copy_in<9>(sHard2, g_bits + 2 * nw, nw, tid);
         ls = a.st_lane[cw];
         __syncthreads();
     }
