@@ -56,6 +56,19 @@ __device__ __forceinline__ void copy_in(uint32_t* dst, const uint32_t* __restric
     }
 }
 
+/* n words from LDS to global memory (or LDS), B reads per lane in flight at a time */
+template <int B>
+__device__ __forceinline__ void copy_out(uint32_t* __restrict__ dst, const uint32_t* src, int n, int tid)
+{
+    for (int i0 = 0; i0 < n; i0 += B * LF_T4) {
+        uint32_t w[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) { const int i = i0 + u * LF_T4 + tid; w[u] = i < n ? src[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < B; ++u) { const int i = i0 + u * LF_T4 + tid; if (i < n) dst[i] = w[u]; }
+    }
+}
+
 /* hard decision En > 0 on the biased bytes (En + 120 >= 121): bit 7 of every byte of x + 7 */
 __device__ __forceinline__ uint32_t hard_flags(uint32_t x) { return x + 0x07070707u; }
 
@@ -82,8 +95,10 @@ __device__ __forceinline__ uint32_t plane_exchange(uint32_t x, uint32_t l5)
 }
 
 template <bool CONF>
-__device__ void build_plane4(CCode c, uint32_t* plane, int thr, int lane)
+__device__ __forceinline__ void build_plane4(CCode c, uint32_t* plane, int thr, int lane)
 {
+    /* (inlined on purpose: as a function of its own the column count is no longer known to be uniform, and every column
+     * becomes a masked branch with an LDS round trip of its own) */
     const int nbc = c->nbc;
     const int th = thr < 1 ? 0 : (thr > 32 ? 32 : thr); /* |En| <= 31: a threshold above 31 means "never" */
     const uint32_t th4 = (uint32_t)th * 0x01010101u;
@@ -91,18 +106,19 @@ __device__ void build_plane4(CCode c, uint32_t* plane, int thr, int lane)
     const uint32_t l5 = (uint32_t)lane & 31u;
     const int word_of_lane = (int)((l5 & 7u) * 8u + 2u * (l5 >> 3) + ((uint32_t)lane >> 5)); /* + cb0 * 8 */
     for (int cb0 = 0; cb0 < nbc; cb0 += 8) {
+        uint32_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) /* columns beyond the last one re-read it; their words are not stored */
+            x[u] = lds4_rd((uint32_t)(cb0 + u < nbc ? cb0 + u : nbc - 1) * 256u + 4u * (uint32_t)lane);
+        __builtin_amdgcn_sched_barrier(0); /* the eight reads in flight together */
         uint32_t g = 0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int cb = cb0 + u;
-            if (cb < nbc) { /* uniform */
-                const uint32_t x = lds4_rd((uint32_t)cb * 256u + 4u * (uint32_t)lane);
-                uint32_t fl;
-                /* En >= thr  <=>  Eb + 8 - thr >= 128;  En <= -thr  <=>  Eb + 7 + thr < 128 (no carries: Eb in [89, 151]) */
-                if (CONF) fl = th == 0 ? 0x80808080u : (((x + b8) - th4) | ~(x + b7 + th4));
-                else fl = hard_flags(x);
-                g |= (fl >> (7 - u)) & (0x01010101u << u); /* bit 7 of byte k -> bit 8 k + u */
-            }
+            uint32_t fl;
+            /* En >= thr  <=>  Eb + 8 - thr >= 128;  En <= -thr  <=>  Eb + 7 + thr < 128 (no carries: Eb in [89, 151]) */
+            if (CONF) fl = th == 0 ? 0x80808080u : (((x[u] + b8) - th4) | ~(x[u] + b7 + th4));
+            else fl = hard_flags(x[u]);
+            g |= (fl >> (7 - u)) & (0x01010101u << u); /* bit 7 of byte k -> bit 8 k + u */
         }
         g = plane_exchange<16>(g, l5);
         g = plane_exchange<8>(g, l5);
@@ -116,20 +132,23 @@ __device__ void build_plane4(CCode c, uint32_t* plane, int thr, int lane)
 
 /* ---- cheap "certainly dirty" test (DecodeMethod 2, see lnsfaid_kernels.hip): parity of the lane's four rows of layer 0
  * straight from En; the XOR of the hard-decision flags is bit 7 of the XOR of the flag words. */
-__device__ bool layer0_dirty4(CCode c, int lane)
+__device__ __forceinline__ bool layer0_dirty4(CCode c, int lane)
 {
     const int deg = c->deg[0];
     const uint32_t tid4 = (uint32_t)lane << 2;
+    uint32_t x4[LF_MAX_DEG], d[LF_MAX_DEG];
+    /* all addresses, then all reads, then the arithmetic: one LDS round trip instead of one per circulant */
+#pragma unroll
+    for (int j = 0; j < LF_MAX_DEG; ++j) x4[j] = j < deg ? tid4 + c->s4tab[0][j] : 0u;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < LF_MAX_DEG; ++j)
+        if (j < deg) d[j] = lds4_rd((x4[j] & 0xfcu) | c->cbtab[0][j]);
+    __builtin_amdgcn_sched_barrier(0);
     uint32_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < LF_MAX_DEG; ++j) {
-        if (j < deg) {
-            const uint32_t sb = c->circ[0][j].sb;
-            const uint32_t x4 = tid4 + ((sb & 255u) << 2);
-            const uint32_t d = lds4_rd((x4 & 0xfcu) | (sb & ~255u));
-            acc ^= hard_flags(__builtin_amdgcn_alignbyte(d, d, x4 >> 8));
-        }
-    }
+    for (int j = 0; j < LF_MAX_DEG; ++j)
+        if (j < deg) acc ^= hard_flags(__builtin_amdgcn_alignbyte(d[j], d[j], x4[j] >> 8));
     return __ballot((acc & 0x80808080u) != 0u) != 0ull;
 }
 
@@ -160,13 +179,32 @@ __device__ __forceinline__ bool group_passed(const int32_t* live, int g, int t, 
 #endif
 }
 
-/* decodedBits of this codeword from the hard-decision plane (CDecoder_FAID.cpp:7091-7102, CDecoder_OMS.cpp:2966-2967) */
+/* decodedBits of this codeword from the hard-decision plane (CDecoder_FAID.cpp:7091-7102, CDecoder_OMS.cpp:2966-2967): one plane
+ * word = 32 output bytes per lane and round, the plane words of all rounds read before the first store */
 __device__ __forceinline__ void write_decoded(const uint32_t* sHard, int8_t* g_out, int N, int tid)
 {
-    uint32_t* out32 = (uint32_t*)g_out;
-    for (int i = tid; i < (N >> 2); i += LF_T4) {
-        const uint32_t bits = (sHard[i >> 3] >> ((i & 7) * 4)) & 15u;
-        out32[i] = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
+    const int nw = N >> 5;
+    if (((size_t)g_out) & 15u) { /* caller's buffer not 16-byte aligned: dword stores */
+        uint32_t* out32 = (uint32_t*)g_out;
+        for (int i = tid; i < (N >> 2); i += LF_T4) out32[i] = (((sHard[i >> 3] >> ((i & 7) * 4)) & 15u) * 0x00204081u) & 0x01010101u;
+        return;
+    }
+    uint4* out = (uint4*)g_out;
+    for (int r0 = 0; r0 * LF_T4 < nw; r0 += 9) {
+        uint32_t w[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) { const int i = (r0 + u) * LF_T4 + tid; w[u] = i < nw ? sHard[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int i = (r0 + u) * LF_T4 + tid;
+            if (i < nw) {
+                uint32_t d[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) d[q] = (((w[u] >> (4 * q)) & 15u) * 0x00204081u) & 0x01010101u; /* bit k -> byte k */
+                out[2 * i] = make_uint4(d[0], d[1], d[2], d[3]);
+                out[2 * i + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+            }
+        }
     }
 }
 
@@ -195,9 +233,11 @@ __device__ void build_erasure_plane4(CCode c, const LfDevCode* gc, uint32_t* pla
 
 /* ---- one layered iteration (lnsfaid_swar.h does the rows) ---- */
 template <int METHOD, bool ERA>
-__device__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, const SwK& K, SwRow* __restrict__ rows, int lane, int it, const uint32_t* sP,
+__device__ __forceinline__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, const SwK& K, SwRow* __restrict__ rows, int lane, int it, const uint32_t* sP,
                            bool have_par, bool lme, uint32_t era_plane)
 {
+    it = __builtin_amdgcn_readfirstlane(it); /* uniform, and the compiler must know it: a divergent iteration number turns the
+                                              * scalar branches and table loads of every layer into masked / per-lane ones */
     const bool fresh = (it == 1); /* no iteration has run yet: every Lmn is still 0, nothing in HBM */
     const int rem = f->max_iter - it;
     const int itx = (it >= 1 && it <= 5) ? it - 1 : 5; /* switch at CDecoder_FAID.cpp:760-779 */
@@ -213,6 +253,10 @@ __device__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, const SwK& K, S
     SwRow cur = zero;
     if (!fresh) cur = rows[lane];
     uint32_t tabv = gc->sbplain[0][lane & 31];
+    /* Nothing may be in flight when the layer loop is entered: the compiler merges the counter state of this path into the
+     * loop header, and with loads pending here it waits in front of every layer as if they still were - in steady state that
+     * is a wait for the row store issued a few instructions earlier (a memory round trip per layer). */
+    __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0) */
     for (int br = 0; br < nbr; ++br) {
         /* next layer's messages and edge table: issued a whole layer ahead of their use; always a valid address (the last
          * layer re-reads layer 0, the first iteration reads what it is about to overwrite and ignores it) */
@@ -276,22 +320,28 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
     const int t_bf0 = max_iter + 1;   /* first bit-flipping decision point */
     const int t_end = t_bf0 + max_bf; /* both loops exhausted               */
 
-    const int my_status = a.status_cur[cw];
+    /* snapshot of the 32 lanes of this group: one load per lane (both halves of the wave hold the same 32 words), everything
+     * else in registers - no LDS round trips in front of the early exits, which most workgroups of a relaunch take */
+    const int g = cw >> 5, lane_in_group = cw & 31;
+    const int sv = a.status_cur[g * LNSFAID_GROUP + (tid & 31)];
+    const int my_status = __builtin_amdgcn_readlane(sv, lane_in_group);
     if (my_status & LF_DONE) { /* uniform exit */
         if (tid == 0) a.status_next[cw] = my_status;
         return;
     }
-    /* snapshot of the 32 lanes of this group */
-    const int g = cw >> 5, lane_in_group = cw & 31;
-    if (tid < LNSFAID_GROUP) sStat[tid] = a.status_cur[g * LNSFAID_GROUP + tid];
     if (tid == LNSFAID_GROUP) sRed[LF_ZERO_SLOT] = 0; /* the word unused synw slots point at */
-    __syncthreads();
-    int kmax = 0, all_same = 1;
-    for (int l = 0; l < LNSFAID_GROUP; ++l) {
-        const int s = sStat[l];
-        kmax = imax(kmax, s & LF_PROG_MASK);
-        all_same &= (s == my_status);
+    int kmax;
+    {
+        int v = sv & LF_PROG_MASK; /* maximum over lanes 0..31, same DPP pattern as add_reduce32 (values are not negative) */
+        v = imax(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+        v = imax(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+        v = imax(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+        v = imax(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+        v = imax(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+        kmax = __builtin_amdgcn_readlane(v, 31);
     }
+    const int all_same = __ballot(sv != my_status) == 0ull;
+    __syncthreads();
     int prog = my_status & LF_PROG_MASK;
 
     uint32_t* g_en = (uint32_t*)(a.st_en + (size_t)cw * (size_t)N);
@@ -432,7 +482,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
             }
             build_plane4<false>(c, sHard, 0, tid);
             /* En is dead from here on: its bytes take hard_ch (= hard) and hard2 */
-            for (int i = tid; i < nw; i += LF_T4) sHard0[i] = sHard[i];
+            copy_out<9>(sHard0, sHard, nw, tid);
             if (METHOD == 5) {
 #pragma unroll
                 for (int k = 0; k < LF_MAX_BC * 8 / LF_T4; ++k) if (tid + k * LF_T4 < nw) sHard2[tid + k * LF_T4] = conf[k];
@@ -487,10 +537,11 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
          * (the syndrome stage has just built the plane from this En; in the bit-flipping stage the plane is the state) as the
          * output for the case that it stops here */
         if (!in_bf) {
-            const uint32_t* src = (const uint32_t*)smem;
-            for (int i = tid; i < (N >> 2); i += LF_T4) g_en[i] = src[i];
+            copy_out<23>(g_en, (const uint32_t*)smem, N >> 2, tid);
         } else {
-            for (int i = tid; i < nw; i += LF_T4) { g_bits[i] = sHard[i]; g_bits[nw + i] = sHard0[i]; g_bits[2 * nw + i] = sHard2[i]; }
+            copy_out<9>(g_bits, sHard, nw, tid);
+            copy_out<9>(g_bits + nw, sHard0, nw, tid);
+            copy_out<9>(g_bits + 2 * nw, sHard2, nw, tid);
             if (tid == 0) a.st_lane[cw] = ls;
         }
         write_decoded(sHard, g_out, N, tid);

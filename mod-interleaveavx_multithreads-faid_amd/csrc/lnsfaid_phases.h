@@ -82,7 +82,7 @@ __device__ __forceinline__ void syn_cache_load(const LfDevCode* gc, int nbr, int
 }
 
 template <int T, bool ROWBITS, bool CACHED = false>
-__device__ int syndrome(CCode c, const LfDevCode* gc, uint32_t* sP, int tid, uint32_t& pA, uint32_t& pB, int* sRed,
+__device__ __forceinline__ int syndrome(CCode c, const LfDevCode* gc, uint32_t* sP, int tid, uint32_t& pA, uint32_t& pB, int* sRed,
                         const SynCache* sc = nullptr)
 {
     typedef const __attribute__((address_space(3))) uint32_t lds_u32;
@@ -172,7 +172,7 @@ __device__ __forceinline__ void bf_cache_load(CCode c, const LfDevCode* gc, int 
 }
 
 template <int T, int METHOD, bool CACHED = false>
-__device__ void bf_step(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, const uint32_t* sHard0, uint32_t* sHard2,
+__device__ __forceinline__ void bf_step(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, const uint32_t* sHard0, uint32_t* sHard2,
                         const uint32_t* sP, int tid, LfLaneState& ls, int* sRed, const BfCache* bc = nullptr)
 {
     const int W = f->W;
@@ -291,7 +291,7 @@ __device__ __forceinline__ uint32_t votes_ge(uint32_t c3, uint32_t c2, uint32_t 
 }
 
 template <int T>
-__device__ void bf_step_plain(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, uint32_t* sCnt, const uint32_t* sP, int tid,
+__device__ __forceinline__ void bf_step_plain(CCode c, CCfg f, const LfDevCode* gc, uint32_t* sHard, uint32_t* sCnt, const uint32_t* sP, int tid,
                               int* sRed)
 {
     const int nw = c->n_words;
