@@ -1,5 +1,8 @@
 /*
- * lnsfaid_kernels.hip — CDNA4 (gfx950) kernels of the batched LDPC decode hot path.
+ * lnsfaid_kernels.hip — the two-rows-per-lane decode kernel and the error-counter kernel (CDNA4, gfx950).
+ * Since round 2 the default decode kernel is lnsfaid_kernel4.hip (four rows per lane, byte-parallel); this one runs DecodeMethod 0
+ * (NMS) and FAID tables that differ between weight classes or are not monotone.  Syndrome and bit flipping
+ * are shared with it through lnsfaid_phases.h.
  *
  * Mapping.  The reference interleaves 32 codewords in the int8 lanes of one AVX register
  * and walks the 3072 check rows serially (CDecoder_FAID.cpp:631-1527).  Here one 128-thread workgroup
@@ -16,8 +19,9 @@
  *     CLDPC.h:123).  A row's outgoing messages are +-c1 on the edge of the first minimum and +-c2 elsewhere:
  *     8 bytes per row {sign bits, argmin, c1, c2} reproduce every Lmn bit for bit; they
  *     stream through global memory one layer ahead of use (16 B per lane, coalesced);
- *   - syndromes are bit-parallel: hard decisions are kept as a bit plane and the parity of 64 rows of a
- *     layer is the XOR of <= 24 rotated 64-bit windows of it (one circulant per lane, DPP XOR-reduction);
+ *   - syndromes are bit-parallel: hard decisions are kept as a bit plane and the parity of 32 rows of a
+ *     layer is the XOR of <= 24 rotated 32-bit windows of it, one lane per (layer, 32 rows) walking a host-built
+ *     table of plane addresses (lnsfaid_phases.h: no cross-lane reduction);
  *   - the bit-flipping stage is bit-sliced: votes of 64 variable nodes are three rotated windows of the
  *     parity plane, added and compared with the threshold by boolean word operations.
  *
