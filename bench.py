@@ -283,7 +283,7 @@ def worker(args):
         alg_bytes = float(sum(32 * algorithmic_bytes(int(i), int(j)) for i, j in stats)) * steps
         return dict(eb_n0=eb_n0, dt=dt, steps=steps, kernel_ms=k_ms, launches=k_launches, alg_bytes=alg_bytes,
                     mean_I=float(stats[:, 0].mean()), mean_J=float(stats[:, 1].mean()), counters=totals,
-                    per_rank_counters=per_rank, n_groups=n_groups)
+                    per_rank_counters=per_rank, n_groups=n_groups, rows_per_lane=(0 if selftest else dec.rows_per_lane()))
 
     # ---- weak leg = headline ---------------------------------------------------------------------------------------
     n_groups = args.groups
@@ -358,7 +358,8 @@ def worker(args):
             "unit": "G wave64 VALU instructions/s",
             "frac": round(ach_ginstr / VALU_PEAK_GINSTR, 4) if ach_ginstr else None,
             "traffic": traffic,
-            "kernel": "lnsfaid_decode_kernel<%d>" % args.method,
+            "kernel": ("lnsfaid_decode4_kernel<%d> (one wave per codeword, four check rows per lane)" if head["rows_per_lane"] == 4
+                       else "lnsfaid_decode_kernel<%d> (128 threads per codeword, two check rows per lane)") % args.method,
             "launches": head["launches"],
             "avg_launch_ms": round(avg_launch_ms, 4),
             "valu_instructions_per_launch": valu_inst,
@@ -376,7 +377,7 @@ def worker(args):
             "note": "measured live: avg_launch_ms (HIP events on the decoder's stream), launches, algorithmic_*; replayed from "
                     "profiles/ (separate rocprofv3 --pmc passes on this exact kernel source, null when the source hash "
                     "differs): valu_instructions_per_launch, traffic.  peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU "
-                    "instruction.  The kernel keeps En in LDS and stores 8-byte compressed rows, so it moves far fewer HBM "
+                    "instruction.  The kernel keeps En in LDS and stores 6 bytes of compressed messages per check row, so it moves far fewer HBM "
                     "bytes than the reference layout's algorithmic figure (SURVEY.md 8(d): 2N + I(4E+N) + J*2N per codeword); "
                     "algorithmic_over_hbm_peak above 1 is therefore not an HBM saturation claim and is not `frac`",
         },
