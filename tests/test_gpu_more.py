@@ -72,6 +72,30 @@ def test_large_batch_device_pointers(abi, code50, method, eb_n0):
     d.close()
 
 
+@pytest.mark.parametrize("off_in,off_out", [(1, 0), (0, 4), (3, 9)])
+def test_unaligned_device_buffers(abi, code50, off_in, off_out):
+    """lnsfaid_decode_device takes any alignment: a fixInput that is not dword aligned goes through the byte-load staging, a
+    decodedBits that is not 16-byte aligned through dword stores; same output as with aligned buffers."""
+    import torch
+    ng, N = 6, code50.N
+    cfg = abi.default_cfg(2, 10)
+    fix = oa.synth_llr(ng, N, 3.6, seed=31)
+    ref, ref_st = oa.decode_mt(code50, cfg, fix, ng)
+    raw_in = torch.zeros(fix.size + 64, dtype=torch.int8, device="cuda")
+    raw_in[off_in:off_in + fix.size] = torch.from_numpy(fix.reshape(-1)).cuda()
+    raw_out = torch.zeros(ng * 32 * N + 64, dtype=torch.int8, device="cuda")
+    d_st = torch.zeros((ng, 2), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert (raw_in.data_ptr() + off_in) % 4 == off_in % 4 and (raw_out.data_ptr() + off_out) % 16 == off_out % 16
+    d = abi.Decoder(code50, cfg, 0, ng)
+    d.decode_device(raw_in.data_ptr() + off_in, ng, raw_out.data_ptr() + off_out, d_st.data_ptr())
+    got = raw_out[off_out:off_out + ng * 32 * N].cpu().numpy().reshape(ref.shape)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(d_st.cpu().numpy(), ref_st)
+    assert int(raw_out[:off_out].abs().sum()) == 0 and int(raw_out[off_out + ng * 32 * N:].abs().sum()) == 0  # nothing outside
+    d.close()
+
+
 def test_baseline_size_batch_properties(abi, code50):
     """BASELINE.json configs[1] size (2048 groups = 65 536 codewords), checked by properties that need no
     oracle run: noiseless codewords are fixed points (zero and the reference's known codeword, mixed per lane),
