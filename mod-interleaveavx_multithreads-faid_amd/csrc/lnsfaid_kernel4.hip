@@ -247,6 +247,7 @@ __device__ __forceinline__ void main_step4(CCode c, CCfg f, const LfDevCode* gc,
     p.f1 = f->factor_1; p.f2 = f->factor_2;
     p.window = rem <= f->floor_iter_thresh;
     p.ef_tables = f->ef >= 1;
+    if (LF4_OMS(METHOD)) sw_oms_tables(p); /* uniform: scalar work, once per iteration */
     const int nbr = c->nbr;
     const SwLds lds = SwLds();
     const SwRow zero = { { 0u, 0u, 0u }, 0u, { 0u, 0u } }; /* Lmn = 0 before the first iteration (CDecoder_FAID.cpp:211-214) */
@@ -454,7 +455,14 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
             const bool needs_checksums = max_iter - prog <= f->floor_iter_thresh; /* never for the shipped DecodeMethod 2: -1 */
             if (needs_checksums || !layer0_dirty4(c, tid)) {
                 build_plane4<false>(c, sHard, 0, tid);
-                const int unsat = syndrome<LF_T4, false>(c, a.code, sP, tid, pA, pB, sRed);
+                int unsat;
+                if (syn_cache_fits(c->nbr)) { /* all table entries of the walk loaded together: one memory round trip, not one per round */
+                    SynCache sc;
+                    syn_cache_load(a.code, c->nbr, tid, sc);
+                    unsat = syndrome<LF_T4, false, true>(c, a.code, sP, tid, pA, pB, sRed, &sc);
+                } else {
+                    unsat = syndrome<LF_T4, false>(c, a.code, sP, tid, pA, pB, sRed);
+                }
                 /* clean on the group's front: park, unless a group mate is known to have passed this point */
                 if (unsat == 0 && prog >= kmax && !group_passed(a.live, g, prog, tid)) { parked = true; break; }
                 if (LF4_OMS(METHOD)) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
@@ -495,16 +503,17 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
     /* ---- bit-flipping iterations.  Nothing of the layer step is alive here, so the lanes keep their entries of the walk
      * tables in registers for the whole stage (no table load, hence no exposed memory latency, per iteration) ---- */
     if (in_bf && !parked) {
-        if (METHOD != 3 && syn_cache_fits(c->nbr) && bf_cache_fits(c, f)) {
+        if (syn_cache_fits(c->nbr) && (METHOD == 3 || bf_cache_fits(c, f))) {
             SynCache sc;
             BfCache bc;
             syn_cache_load(a.code, c->nbr, tid, sc);
-            bf_cache_load(c, a.code, tid, bc);
+            if (METHOD != 3) bf_cache_load(c, a.code, tid, bc);
             while (prog < t_end) {
                 const int unsat = syndrome<LF_T4, false, true>(c, a.code, sP, tid, pA, pB, sRed, &sc);
                 if (unsat == 0 && prog >= kmax && !group_passed(a.live, g, prog, tid)) { parked = true; break; }
                 publish_pass(a.live, cw, prog, tid);
-                bf_step<LF_T4, METHOD, true>(c, f, a.code, sHard, sHard0, sHard2, sP, tid, ls, sRed, &bc);
+                if (METHOD == 3) bf_step_plain<LF_T4>(c, f, a.code, sHard, sHard2 + nw /* 4 count planes in the dead En */, sP, tid, sRed);
+                else bf_step<LF_T4, METHOD, true>(c, f, a.code, sHard, sHard0, sHard2, sP, tid, ls, sRed, &bc);
                 prog++;
             }
         } else {

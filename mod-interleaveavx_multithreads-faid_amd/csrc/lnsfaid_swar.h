@@ -177,6 +177,9 @@ struct SwParams {
     int32_t f1, f2;                /* Factor_1 / Factor_2 (OMS offsets, NMS numerators)                          */
     int32_t window;                /* nombre_iterations <= floor_iter_thresh                                     */
     int32_t ef_tables;             /* EF_ELIMINATION >= 1 (always so for DecodeMethod 5; 0, 1 or 2 for DecodeMethod 2)  */
+    uint32_t oms_lo[2], oms_hi[2]; /* min-sum decoders: the selective offset + clamp as 8-entry byte tables over the minimum
+                                    * (0..7), [0] the ordinary rule, [1] the rule of an unsatisfied row inside the window
+                                    * (sw_oms_tables fills them from f1 / f2)                                         */
 };
 
 /* LDS seen by the layer step: byte offsets inside the codeword's En image (block column cb at cb * 256). */
@@ -219,6 +222,20 @@ SW_FN int sw_oms_offset(int x, bool window, bool F, int f1, int f2)
         if (x >= f2) x -= 1;
     }
     return x;
+}
+
+/* CDecoder_OMS.cpp:388-432 as two tables: entry x = min(offset(x), SAT_POS_MSG) for both branches of the rule */
+SW_FN void sw_oms_tables(SwParams& p)
+{
+    for (int r = 0; r < 2; ++r) {
+        uint32_t lo = 0, hi = 0;
+        for (int x = 0; x < 8; ++x) {
+            const int a = sw_oms_offset(x, r != 0, r != 0, p.f1, p.f2);
+            const uint32_t v = (uint32_t)((a > 7 ? 7 : a) & 0xff);
+            if (x < 4) lo |= v << (8 * x); else hi |= v << (8 * (x - 4));
+        }
+        p.oms_lo[r] = lo; p.oms_hi[r] = hi;
+    }
 }
 
 /* the two-stage saturating update En' = sat31(tc + L), tc = sat31(t) (FAID, CDecoder_FAID.cpp:672, :919-920) or
@@ -405,13 +422,13 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
     uint32_t c1n, c2n;
     static_assert(METHOD != 0, "NMS keeps |t| up to 31 in its minima: it runs on the two-rows-per-lane kernel");
     if (SW_OMS(METHOD)) {
-        c2n = 0; c1n = 0;
-        for (int k = 0; k < 4; ++k) {
-            const bool F = ((rowpar >> (8 * k)) & 1u) && lme;
-            int a = sw_oms_offset((int)((min1 >> (8 * k)) & 0xffu), p.window != 0, F, p.f1, p.f2);
-            int b = sw_oms_offset((int)((min2 >> (8 * k)) & 0xffu), p.window != 0, F, p.f1, p.f2);
-            c2n |= (uint32_t)((a > 7 ? 7 : a) & 0xff) << (8 * k); /* cste_2, CDecoder_OMS.cpp:432 */
-            c1n |= (uint32_t)((b > 7 ? 7 : b) & 0xff) << (8 * k); /* cste_1 */
+        /* selective offset and clamp (cste_2 from min1, cste_1 from min2, CDecoder_OMS.cpp:431-432) as table look-ups; rows
+         * with an unsatisfied check take the other rule inside the error-floor window of a codeword with few of them (:388) */
+        c2n = sw_perm(p.oms_hi[0], p.oms_lo[0], min1);
+        c1n = sw_perm(p.oms_hi[0], p.oms_lo[0], min2);
+        if (p.window && lme) {
+            c2n = sw_bitop3<SW_TT_SEL>(rowpar, sw_perm(p.oms_hi[1], p.oms_lo[1], min1), c2n);
+            c1n = sw_bitop3<SW_TT_SEL>(rowpar, sw_perm(p.oms_hi[1], p.oms_lo[1], min2), c1n);
         }
     } else {
         /* uniform non-decreasing table applied after the search; offset 0 (CDecoder_FAID.cpp:864-866) */

@@ -97,6 +97,7 @@ extern "C" int swar_emul_layered(const lnsfaid_code* code, const lnsfaid_cfg* cf
             p.f1 = (int8_t)cfg->factor_1; p.f2 = (int8_t)cfg->factor_2;
             p.window = rem <= cfg->floor_iter_thresh;
             p.ef_tables = cfg->ef_elimination >= 1;
+            sw_oms_tables(p);
             /* EF_ELIMINATION 2: erase in this iteration?  plane bit v = all checks of v unsatisfied (weight-W columns) */
             const int W = cfg->regular_col_weight;
             const bool erase = method == 2 && cfg->ef_elimination == 2 && p.window && lme;

@@ -17,7 +17,8 @@ EMU = os.path.join(oa.ORACLE_DIR, "libswar_emul.so")
 
 class SwParams(C.Structure):
     _fields_ = [("lut_lo", C.c_uint32), ("lut_hi", C.c_uint32), ("ef_lo", C.c_uint32), ("ef_hi", C.c_uint32),
-                ("f1", C.c_int32), ("f2", C.c_int32), ("window", C.c_int32), ("ef_tables", C.c_int32)]  # = struct SwParams
+                ("f1", C.c_int32), ("f2", C.c_int32), ("window", C.c_int32), ("ef_tables", C.c_int32),
+                ("oms_lo", C.c_uint32 * 2), ("oms_hi", C.c_uint32 * 2)]  # = struct SwParams (the tables: min-sum decoders only)
 
 
 def test_instruction_semantics_match_the_host_restatements():
@@ -74,7 +75,7 @@ def test_layer_step_on_the_device_equals_the_cpu_run(abi, code50, n_iter):
                 lo |= val << (8 * a)
             else:
                 hi |= val << (8 * (a - 4))
-        p6[it] = SwParams(lo, hi, 0, 0, 0, 0, 0, 0)
+        p6[it] = SwParams(lo, hi, 0, 0, 0, 0, 0, 0, (C.c_uint32 * 2)(0, 0), (C.c_uint32 * 2)(0, 0))
     assert dev.swar_devtest_layers(32, N, nbr, deg.ctypes.data_as(C.c_void_p), sb.ctypes.data_as(C.c_void_p), p6, n_iter,
                                    img.ctypes.data_as(C.c_void_p)) == 0
     got = (img[:, pos].astype(np.int16) - 120).astype(np.int8).reshape(-1)
