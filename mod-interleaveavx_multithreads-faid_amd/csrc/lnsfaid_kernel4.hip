@@ -453,7 +453,10 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
              * (nombre_iterations <= floor_iter_thresh: OMS selective offset CDecoder_OMS.cpp:388, 2B1C tables
              * CDecoder_FAID.cpp:714) and never by DecodeMethod 2; elsewhere only unsat != 0 matters */
             const bool needs_checksums = max_iter - prog <= f->floor_iter_thresh; /* never for the shipped DecodeMethod 2: -1 */
-            if (needs_checksums || !layer0_dirty4(c, tid)) {
+            /* behind the group's front (the snapshot shows a lane parked beyond this point) the group is known to go on, and
+             * outside the window nothing else reads the syndrome: a catching-up codeword skips the stage altogether */
+            const bool must_know = needs_checksums || prog >= kmax;
+            if (must_know && (needs_checksums || !layer0_dirty4(c, tid))) {
                 build_plane4<false>(c, sHard, 0, tid);
                 int unsat;
                 if (syn_cache_fits(c->nbr)) { /* all table entries of the walk loaded together: one memory round trip, not one per round */
