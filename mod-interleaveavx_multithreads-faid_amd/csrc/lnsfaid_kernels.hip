@@ -725,10 +725,18 @@ __global__ __launch_bounds__(256) void lnsfaid_count_errors_kernel(const int8_t*
         if (WIDE) {
             const uint4* d4 = (const uint4*)d;
             const uint4* r4 = (const uint4*)r;
-            for (int j = lane; j < (k_info >> 4); j += 64) {
-                uint4 x = d4[j];
-                if (r) { const uint4 y = r4[j]; x.x ^= y.x; x.y ^= y.y; x.z ^= y.z; x.w ^= y.w; }
-                cnt += nonzero_bytes(x.x) + nonzero_bytes(x.y) + nonzero_bytes(x.z) + nonzero_bytes(x.w);
+            /* eight 16-byte loads per lane in flight before the first use (a plain loop waits for every load in turn) */
+            const int n16 = k_info >> 4;
+            for (int j0 = 0; j0 < n16; j0 += 8 * 64) {
+                uint4 x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u * 64 + lane;
+                    x[u] = j < n16 ? d4[j] : make_uint4(0u, 0u, 0u, 0u);
+                    if (r && j < n16) { const uint4 y = r4[j]; x[u].x ^= y.x; x[u].y ^= y.y; x[u].z ^= y.z; x[u].w ^= y.w; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cnt += nonzero_bytes(x[u].x) + nonzero_bytes(x[u].y) + nonzero_bytes(x[u].z) + nonzero_bytes(x[u].w);
             }
         } else {
             const uint32_t* d1 = (const uint32_t*)d;
