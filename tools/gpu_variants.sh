@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 for v in "$@"; do
   name="${v%%:*}"; flags="${v#*:}"
-  rm -f mod-interleaveavx_multithreads-faid_amd/csrc/lnsfaid_kernels.o mod-interleaveavx_multithreads-faid_amd/csrc/lnsfaid_kernel4.o
+  rm -f mod-interleaveavx_multithreads-faid_amd/csrc/lnsfaid_kernels.o mod-interleaveavx_multithreads-faid_amd/csrc/lnsfaid_kernel4.o mod-interleaveavx_multithreads-faid_amd/csrc/lnsfaid_capi.o
   make -s -C mod-interleaveavx_multithreads-faid_amd/csrc HIPFLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -I. $flags" > gpurun_out/variant_$name.build.log 2>&1 || { echo "$name: build failed"; continue; }
   timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu ${POINTS:---no-points} $BENCH_ARGS 2>/dev/null | python -c "
 import json,sys
