@@ -5,11 +5,14 @@
  * line and the park / relaunch rules); what differs is how a layer is computed:
  *   - lane i owns rows i, i + 64, i + 128, i + 192 of every layer; byte k of a working register belongs to row i + 64 k and
  *     the layer step is carry-free byte-parallel arithmetic on plain 32-bit operations (lnsfaid_swar.h) instead of two rows on
- *     packed 16-bit operations: ~1200 VALU instructions per layer of 256 rows, three quarters of them of the full-rate class,
- *     against 2 x 615 with three quarters of the half-rate class;
+ *     packed 16-bit operations: 928 VALU instructions per layer of 256 rows, 70 % of them of the full-rate class, against
+ *     2 x 615 with three quarters of the half-rate class;
  *   - En is kept in LDS interleaved (variable node v of a block column in dword v mod 64, byte v div 64, biased by 120), so an
  *     edge is one ds_read_b32 + one byte rotation for four rows, and a workgroup is a single wave: no barrier between layers;
  *   - the compressed messages of a lane's four rows are 24 bytes per layer (SwRow).
+ * One wave per codeword means two waves per SIMD (the LDS image of a codeword allows 8 per CU), and with two waves nothing hides a
+ * stall: every loop that loads keeps all its loads in flight before the first use, the walk tables of the bit-flipping stage live in
+ * registers, and everything on the hot path is inlined (tests/test_kernel_isa.py holds these properties).
  * Used for DecodeMethods 1..5 whenever the FAID tables are uniform over the weight classes and non-decreasing (every shipped
  * set); DecodeMethod 0 and other tables run on the two-rows-per-lane kernel.
  */

@@ -18,8 +18,11 @@
  *                   (CDecoder_FAID.cpp:682: t == 0 means En == Lold, so sign(En) is the stored sign bit)
  *   minima          thermometer code U(a), a = min(|t|, 7): bit i set iff a > i, so min = AND and
  *                   second-min' = second-min & (min | U): two boolean operations per edge for four rows; the binary
- *                   index of an edge attaining the minimum comes from five more AND accumulators (edges whose index
- *                   has bit b clear) compared with the minimum afterwards — no per-edge compare / select.
+ *                   index of an edge attaining the minimum comes from five more AND accumulators (index bits 0..2: over
+ *                   the edges with the bit clear, bits 3 and 4: over the fewer edges with it set) compared with the minimum
+ *                   afterwards — no per-edge compare / select.
+ *   update          En' = clamp(z, -31, 31 - c) + (L < 0 ? 0 : c) with z = t - (L < 0 ? c : 0): limits independent of the sign
+ *                   of the new message L = +-c (sw_update)
  * Reference statements restated here: CDecoder_FAID.cpp:662-929 (FAID / 2B1C rows), CDecoder_OMS.cpp:363-471 (OMS rows),
  * CLDPC.cpp:296-375 (NMS rows).  As in the 2-rows-per-lane kernel the check-to-variable messages are kept compressed
  * (sign bit per edge, the two magnitudes of the row, the edge that carries the larger one) and only ONE edge per row
