@@ -374,9 +374,10 @@ def test_host_driver_resume_from_temp_txt(abi, code50, tmp_path, extra):
     assert got == want, (got, want, res2.stdout)
 
 
-def _derived_code(abi, lib, drop_cols, from_block_row):
+def _derived_code(abi, lib, drop_cols, from_block_row, keep_edges=None):
     """A second quasi-cyclic code for the generic code paths: the 50G-PON table with the circulants of the
-    block columns `drop_cols` removed from block rows >= from_block_row (degree 23 -> 23 - len(drop_cols))."""
+    block columns `drop_cols` removed from block rows >= from_block_row (degree 23 -> 23 - len(drop_cols)); `keep_edges`
+    {block row: n} keeps only the first n circulants of a block row."""
     import ctypes as C
     base = abi.Code50GPON(lib)
     pos = np.ctypeslib.as_array(base.pos_vn)
@@ -388,6 +389,8 @@ def _derived_code(abi, lib, drop_cols, from_block_row):
         e += d
         if r // 256 >= from_block_row:
             row = row[~np.isin(row // 256, drop_cols)]
+        if keep_edges and r // 256 in keep_edges:
+            row = row[:keep_edges[r // 256]]
         out.append(row)
         degs.append(len(row))
     classes, rows = [], []
@@ -425,6 +428,23 @@ def test_other_code_with_runtime_row_degree(abi, lib, method):
     out, st = d.decode(fix, 3)
     d.close()
     assert np.array_equal(out, ref) and np.array_equal(st, rst)
+
+
+@pytest.mark.parametrize("method", [2, 1])
+def test_other_code_with_low_row_degrees(abi, lib, method):
+    """Block rows of degree 12, 7 and 3 next to the full ones: the run-time-degree layer step with no edge in 16..23 / 8..15 (the
+    arg-min index takes its bits 4 and 3 from those ranges), and rows shorter than one 8-edge sign word."""
+    dc = _derived_code(abi, lib, [], 12, keep_edges={9: 12, 10: 7, 11: 3})
+    assert sorted(set(dc.deg)) == [3, 7, 12, 22, 23]
+    cfg = abi.default_cfg(method, 10)
+    fix = oa.synth_llr(3, dc.N, 4.6, seed=77 + method)
+    ref, rst = oa.decode_mt(dc, cfg, fix, 3)
+    d = abi.Decoder(dc, cfg, 0, 3)
+    assert d.rows_per_lane() == 4
+    out, st = d.decode(fix, 3)
+    d.close()
+    assert np.array_equal(out, ref) and np.array_equal(st, rst)
+    assert (ref != 0).any()  # (the weakened code leaves errors: the comparison is not all-zero against all-zero)
 
 
 @pytest.mark.parametrize("method,alpha,W,L0,delta", [(2, 2, 3, 50, 1), (2, 1, 6, 3, 1), (5, 0, 3, 2, 2), (5, 3, 3, 100, 1)])
