@@ -33,7 +33,30 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+PKG_DIR = os.path.join(ROOT, "mod-interleaveavx_multithreads-faid_amd")
+
+
+def load_pkg_module(name):
+    """The package directory name is not a Python identifier: its modules (pyabi.py, dist.py) are imported by path."""
+    import importlib.util
+    if "lnsfaid_" + name in sys.modules:
+        return sys.modules["lnsfaid_" + name]
+    spec = importlib.util.spec_from_file_location("lnsfaid_" + name, os.path.join(PKG_DIR, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["lnsfaid_" + name] = mod  # one instance per process: ctypes structure classes are compared by identity
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_oracle_abi():
+    """tests/oracle_abi.py: the ctypes view of oracle/ (test infrastructure).  Imported ONLY by the cpu_baseline leg and by the
+    CPU-only --launcher-selftest; the measured path never sees it."""
+    tests_dir = os.path.join(ROOT, "tests")
+    if tests_dir not in sys.path:
+        sys.path.insert(0, tests_dir)
+    import oracle_abi
+    return oracle_abi
+
 
 N_VAR, N_CHECK, N_EDGES = 17664, 3072, 70400
 K_INFO = N_VAR - N_CHECK
@@ -83,6 +106,21 @@ def synth_llr(torch, device, n_groups, eb_n0, seed, mod_type=2, scale=13.0):
     return out
 
 
+def host_cores():
+    """Cores this process may run on: the affinity mask, cut down to the cgroup's CPU quota where one is set."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -108,7 +146,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-points", action="store_true", help="skip the 3.6 / 4.2 dB side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling leg")
-    ap.add_argument("--cpu-groups", type=int, default=1024, help="groups of the cpu_baseline sample per Eb/N0 point")
+    ap.add_argument("--cpu-groups", type=int, default=2048, help="groups of the cpu_baseline sample per Eb/N0 point")
+    ap.add_argument("--cpu-seconds", type=float, default=1.0, help="minimum wall time of the cpu_baseline leg per Eb/N0 point")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="cap on the cpu_baseline threads (0: every core this process may use)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="counter all-reduce transport (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="let several ranks use one GPU (rank -> device rank %% device_count; rehearsal on a one-GPU box, "
@@ -179,12 +219,9 @@ class SelftestDecoder:
 def worker(args):
     import numpy as np
     import torch
-    import oracle_abi as oa
-    pyabi = oa.pyabi
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("lnsfaid_dist", os.path.join(oa.PKG_DIR, "dist.py"))
-    lnsfaid_dist = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(lnsfaid_dist)
+    pyabi = load_pkg_module("pyabi")
+    lnsfaid_dist = load_pkg_module("dist")
+    oa = load_oracle_abi() if args.launcher_selftest else None  # the GPU legs do not import it (cpu_baseline does, below)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -226,6 +263,43 @@ def worker(args):
     else:
         dec = pyabi.Decoder(code, cfg, device=dev_index, max_groups=args.groups, lib=lib)
 
+    # ---- how the four error counters are summed over the ranks (the path's only exchange, reference main.cpp:174-182) --------
+    # N > 1 with one GPU per rank: the PRODUCT's reduction - rank 0 makes an RCCL id (lnsfaid_comm_unique_id), the 128 bytes travel
+    # through the torch.distributed store, every rank joins with lnsfaid_comm_init, and every step calls
+    # lnsfaid_allreduce_counters (one ncclAllReduce of 4 x uint64 on the decoder's stream).  torch.distributed stays for the
+    # barrier, the MAX over the ranks' times and the gather of per-rank lines.  Ranks that share a GPU (--share-gpu rehearsal)
+    # and the CPU self-test cannot form an RCCL communicator (one rank per device) and sum over gloo; N = 1 has nothing to sum.
+    reduce_via = "none (world size 1: no collective)"
+    if world > 1 and not selftest and backend == "nccl":
+        import ctypes
+        cid = (ctypes.c_uint8 * 128)()
+        if rank == 0:
+            rc = lib.lnsfaid_comm_unique_id(cid)
+            if rc != 0:
+                raise SystemExit("lnsfaid_comm_unique_id failed: %d" % rc)
+        box = [bytes(cid) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        cid = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+        dec.comm_init(world, rank, cid)
+        reduce_via = "lnsfaid_allreduce_counters"
+    elif dist is not None and world > 1:
+        reduce_via = "torch.distributed gloo"
+    elif dist is not None and backend == "nccl" and not selftest:
+        # world of one under the launcher: still the product's RCCL path, on a communicator of one rank
+        import ctypes
+        cid = (ctypes.c_uint8 * 128)()
+        if lib.lnsfaid_comm_unique_id(cid) != 0:
+            raise SystemExit("lnsfaid_comm_unique_id failed")
+        dec.comm_init(1, 0, cid)
+        reduce_via = "lnsfaid_allreduce_counters"
+
+    def reduce_counters(local):
+        if reduce_via == "lnsfaid_allreduce_counters":
+            return [int(c) for c in dec.allreduce_counters(local)]
+        if reduce_via == "torch.distributed gloo":
+            return lnsfaid_dist.allreduce_counters(local, dist, red_device)
+        return [int(c) for c in local]
+
     def sync():
         if not selftest:
             torch.cuda.synchronize()
@@ -258,8 +332,7 @@ def worker(args):
             else:
                 dec.decode_device(d_fix.data_ptr(), n_groups, d_out.data_ptr(), d_stats.data_ptr())
                 local = dec.count_errors_device(d_out.data_ptr(), None, n_groups)
-            # all-reduce of the 4 counters: the path's only exchange (reference main.cpp:174-182)
-            totals = lnsfaid_dist.allreduce_counters(local, dist, red_device)
+            totals = reduce_counters(local)  # the path's only exchange (reference main.cpp:174-182)
 
         for _ in range(warmup):
             step()
@@ -272,18 +345,22 @@ def worker(args):
         dt = time.perf_counter() - t0
         k_ms, k_launches = dec.kernel_time(reset=True)
         per_rank = [local]
+        per_rank_ms = [round(dt / steps * 1e3, 4)]
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=red_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank's time
-            dt = float(t.item())
             gathered = [None] * world
-            dist.all_gather_object(gathered, [int(c) for c in local])
-            per_rank = gathered
+            dist.all_gather_object(gathered, ([int(c) for c in local], round(dt / steps * 1e3, 4)))
+            per_rank = [g[0] for g in gathered]
+            per_rank_ms = [g[1] for g in gathered]
+            dt = float(t.item())
         stats = host_stats if selftest else d_stats.cpu().numpy()
         alg_bytes = float(sum(32 * algorithmic_bytes(int(i), int(j)) for i, j in stats)) * steps
         return dict(eb_n0=eb_n0, dt=dt, steps=steps, kernel_ms=k_ms, launches=k_launches, alg_bytes=alg_bytes,
                     mean_I=float(stats[:, 0].mean()), mean_J=float(stats[:, 1].mean()), counters=totals,
-                    per_rank_counters=per_rank, n_groups=n_groups, rows_per_lane=(0 if selftest else dec.rows_per_lane()))
+                    per_rank_counters=per_rank, per_rank_ms=per_rank_ms, n_groups=n_groups,
+                    rows_per_lane=(0 if selftest else dec.rows_per_lane()),
+                    message_store=(0 if selftest else dec.message_store()))
 
     # ---- weak leg = headline ---------------------------------------------------------------------------------------
     n_groups = args.groups
@@ -344,12 +421,15 @@ def worker(args):
             "eb_n0_db": args.eb_n0,
             "mean_layered_iterations": head["mean_I"],
             "mean_bf_iterations": head["mean_J"],
-            "parallelism": "one process per GPU, whole groups per rank, no data-path collective; %s all-reduce of 4 error "
-                           "counters per step (world size %d)" % ("RCCL" if backend == "nccl" else "gloo", world),
+            "parallelism": ("one process per GPU, whole groups per rank, no data-path collective; the 4 error counters are summed "
+                            "once per step by %s (world size %d)" % (reduce_via, world)) if world > 1 or reduce_via != "none (world size 1: no collective)"
+                           else "one GPU, one process: no collective ran (the counters of the one rank are the totals)",
             "world_size": world,
-            "backend": backend,
+            "reduce": reduce_via,
+            "backend": backend if dist is not None else "none (no process group at N = 1 without the launcher)",
             "counters_TestFrame_ErrorFrame_ErrorBits_LT3": head["counters"],
             "per_rank_counters": head["per_rank_counters"],
+            "per_rank_ms_per_step": head["per_rank_ms"],
         },
         "roofline": {
             "bound": "valu-issue",
@@ -394,12 +474,12 @@ def worker(args):
         else:  # more ranks than groups: this rank only joins the collectives
             sp = None
             for _ in range(1 + args.steps):
-                lnsfaid_dist.allreduce_counters([0, 0, 0, 0], dist, red_device)
+                reduce_counters([0, 0, 0, 0])
             barrier(); barrier()
             t = torch.tensor([0.0], dtype=torch.float64, device=red_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             gathered = [None] * world
-            dist.all_gather_object(gathered, [0, 0, 0, 0])
+            dist.all_gather_object(gathered, ([0, 0, 0, 0], 0.0))
         if rank == 0 and sp is not None:
             result["strong"] = {
                 "value": round(args.groups * 32 * K_INFO * args.steps / sp["dt"] / 1e9, 4), "unit": "Gb/s",
@@ -407,6 +487,7 @@ def worker(args):
                 "ms_per_step": round(sp["dt"] / args.steps * 1e3, 4),
                 "counters_TestFrame_ErrorFrame_ErrorBits_LT3": sp["counters"],
                 "per_rank_counters": sp["per_rank_counters"],
+                "per_rank_ms_per_step": sp["per_rank_ms"],
             }
 
     if rank == 0 and world == 1 and not args.no_points and not selftest:
@@ -421,10 +502,12 @@ def worker(args):
         result["points"] = pts
 
     if rank == 0 and world == 1 and not args.no_cpu and not selftest:
-        # bounded CPU samples of the same workload: the first cpu_groups groups of a batch at each of the three Eb/N0
-        # points, decoded once by the AVX2 port on the host cores; the GPU result of the same groups is
-        # compared bit for bit
-        threads = max(1, min(os.cpu_count() or 1, 16))
+        # cpu_baseline: the AVX2 port (oracle/, test infrastructure - imported here and nowhere else in the GPU legs) on ALL host
+        # cores this process may use, one group stream per thread, at the three Eb/N0 points.  Per point the sample is the whole
+        # batch the GPU has just decoded (every frame compared with the GPU's), and the pass is repeated until the point has
+        # run for at least --cpu-seconds of wall time.
+        oa = load_oracle_abi()
+        threads = max(1, min(host_cores(), args.cpu_threads or 1 << 30))
         ng = min(args.cpu_groups, n_groups)
         d_out = torch.empty((n_groups, 32 * N_VAR), dtype=torch.int8, device=device)
         d_stats = torch.zeros((n_groups, 2), dtype=torch.int32, device=device)
@@ -439,21 +522,27 @@ def worker(args):
             gpu_dec = d_out[:ng].cpu().numpy().reshape(-1)
             gpu_stats = d_stats[:ng].cpu().numpy()
             del d_fix
-            t0 = time.perf_counter()
-            cpu_dec, cpu_stats = oa.decode_mt(code, cfg, fix_host, ng, threads=threads, kind="avx2")
-            dt = time.perf_counter() - t0
-            samples.append({"eb_n0_db": eb, "value": round(ng * 32 * K_INFO / dt / 1e9, 5), "unit": "Gb/s", "wall_s": round(dt, 2),
-                            "cpu_work_s": round(dt * threads, 1),
-                            "parity_with_gpu": bool(np.array_equal(cpu_dec, gpu_dec) and np.array_equal(cpu_stats, gpu_stats))})
+            passes, dt, parity = 0, 0.0, True
+            while passes == 0 or (dt < args.cpu_seconds and passes < 64):
+                t0 = time.perf_counter()
+                cpu_dec, cpu_stats = oa.decode_mt(code, cfg, fix_host, ng, threads=threads, kind="avx2")
+                dt += time.perf_counter() - t0
+                if passes == 0:
+                    parity = bool(np.array_equal(cpu_dec, gpu_dec) and np.array_equal(cpu_stats, gpu_stats))
+                passes += 1
+            samples.append({"eb_n0_db": eb, "value": round(passes * ng * 32 * K_INFO / dt / 1e9, 5), "unit": "Gb/s", "wall_s": round(dt, 2),
+                            "passes": passes, "cpu_work_s": round(dt * threads, 1), "parity_with_gpu": parity})
         result["cpu_baseline"] = {
             "value": samples[0]["value"],
             "unit": "Gb/s",
             "cores": threads,
+            "host_cpu_count": os.cpu_count(),
             "cpu_model": cpu_model(),
             "kind": "port",
-            "sample": "per Eb/N0 point the first %d groups (%d codewords) of a %d-codeword batch, decoded once by "
-                      "oracle/lnsfaid_cpu_avx2.c on %d host threads (one group stream per thread); `value` is the %.1f dB point"
-                      % (ng, ng * 32, n_cw, threads, args.eb_n0),
+            "sample": "per Eb/N0 point %d groups (%d codewords: %s batch the GPU decoded), decoded by oracle/lnsfaid_cpu_avx2.c on %d "
+                      "host threads (every core this process may run on; one group stream per thread), the pass repeated until the "
+                      "point has run >= %.1f s of wall time; `value` is the %.1f dB point"
+                      % (ng, ng * 32, "the whole" if ng == n_groups else "the first groups of the", threads, args.cpu_seconds, args.eb_n0),
             "points": samples,
             "parity_with_gpu": all(s["parity_with_gpu"] for s in samples),
             "note": "the port is an upper bound for the reference on this host: AVX2 with 32 codewords per 256-bit register like "

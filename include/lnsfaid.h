@@ -259,6 +259,24 @@ int lnsfaid_allreduce_counters(lnsfaid_ctx* ctx, uint64_t counters[4]);
 int lnsfaid_select_kernel(lnsfaid_ctx* ctx, int32_t rows_per_lane);
 int lnsfaid_kernel_rows_per_lane(const lnsfaid_ctx* ctx);
 
+/* Where the four-rows-per-lane kernel keeps the check-to-variable messages (the reference's var_msgs, CLDPC.h:123,
+ * lifetime CDecoder_FAID.cpp:211-214 ... :923) between the layers of a launch.  LNSFAID_MSG_REGISTERS: the compressed messages
+ * of the codeword (72 dwords per lane for the 12 layers of the 50G-PON code) stay in the wavefront's registers for the whole
+ * launch and reach HBM only when a codeword parks - no vector-memory operation inside the layer loop; available for codes of
+ * up to 12 layers, not for EF_ELIMINATION 2.  LNSFAID_MSG_HBM: streamed through HBM one layer ahead of use (every code).
+ * 0 (default): registers where available.  Identical results either way; the switch exists for tests and A/B timing.
+ * lnsfaid_message_store returns what the next decode will use. */
+#define LNSFAID_MSG_REGISTERS 1
+#define LNSFAID_MSG_HBM 2
+int lnsfaid_select_message_store(lnsfaid_ctx* ctx, int32_t where);
+int lnsfaid_message_store(const lnsfaid_ctx* ctx);
+
+/* Workgroups (codewords) of the selected decode kernel a compute unit holds at once, from the HIP occupancy query, next to
+ * what the kernel's LDS footprint alone would allow (50G-PON: 8 and 8).  A smaller first number means a build lost residency to
+ * registers - about 40 % of the throughput for the one-wave-per-codeword kernel.  Also checks that the kernel has no static LDS
+ * (LNSFAID_E_INTERNAL otherwise; every decode call checks the same once per kernel instance). */
+int lnsfaid_kernel_residency(lnsfaid_ctx* ctx, int32_t* workgroups_per_cu, int32_t* lds_limit);
+
 /* ---- measurement hooks ------------------------------------------------------- */
 
 /* Device time (HIP events on the context's stream) and launch count of the

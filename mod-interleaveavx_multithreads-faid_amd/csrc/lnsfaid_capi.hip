@@ -20,7 +20,12 @@
 
 extern "C" hipError_t lf_launch_decode(int method, int uniform_w, const LfKernelArgs* args, size_t lds_bytes,
                                        hipStream_t stream);
-extern "C" hipError_t lf_launch_decode4(int method, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream);
+extern "C" const void* lf_decode_func(int method, int uniform_w);
+extern "C" int lf_decode_threads(void);
+extern "C" const void* lf_decode4_func(int method, int ef, int rm);
+extern "C" int lf_decode4_threads(void);
+extern "C" hipError_t lf_launch_decode4(int method, int ef, int rm, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream);
+extern "C" int lf_decode4_rm_layers(void);
 extern "C" hipError_t lf_launch_count_errors(const int8_t* decoded, const int8_t* input_bits, int n_var, int k_info,
                                              size_t n_cw, unsigned long long* out, hipStream_t stream);
 
@@ -71,6 +76,9 @@ struct lnsfaid_ctx {
     int8_t* d_io_out = nullptr;
     lnsfaid_group_stats* d_io_stats = nullptr;
     int rows_per_lane = 0; /* 0: pick per configuration; 2 / 4: forced (lnsfaid_select_kernel) */
+    int msg_store = 0;     /* 0: pick per code; 1: registers; 2: streamed through HBM (lnsfaid_select_message_store) */
+    const void* checked_fn = nullptr; /* kernel instance kernel_check() last looked at */
+    int resident_wg = 0, lds_wg = 0;  /* its workgroups per CU: what the occupancy query says / what its LDS alone allows */
     void* comm = nullptr;      /* ncclComm_t for lnsfaid_allreduce_counters */
     bool comm_owned = false;
     unsigned long long* d_reduce = nullptr;
@@ -326,6 +334,8 @@ extern "C" int lnsfaid_create(lnsfaid_ctx** out, const lnsfaid_code* code, const
     ctx->max_groups = max_groups;
     if (const char* e = getenv("LNSFAID_ROWS_PER_LANE")) /* test / A-B switch: force the 2-rows-per-lane kernel for a whole run */
         ctx->rows_per_lane = (e[0] == '2') ? 2 : 0;
+    if (const char* e = getenv("LNSFAID_MSG_STORE")) /* test / A-B switch, see lnsfaid_select_message_store */
+        ctx->msg_store = (e[0] == 'h') ? LNSFAID_MSG_HBM : ((e[0] == 'r') ? LNSFAID_MSG_REGISTERS : 0);
     const int rc = create_impl(ctx, code, cfg);
     if (rc) { lnsfaid_destroy(ctx); return rc; }
     *out = ctx;
@@ -380,6 +390,91 @@ extern "C" int lnsfaid_select_kernel(lnsfaid_ctx* ctx, int32_t rows_per_lane)
 
 extern "C" int lnsfaid_kernel_rows_per_lane(const lnsfaid_ctx* ctx) { return ctx ? (use_kernel4(ctx) ? 4 : 2) : LNSFAID_E_INVAL; }
 
+/* Where the four-rows kernel keeps the compressed check-to-variable messages between layers: in registers (codes of up to
+ * lf_decode4_rm_layers() layers; not built for the erasing instance of EF_ELIMINATION 2) or streamed through HBM. */
+static bool msg_registers_possible(const lnsfaid_ctx* ctx)
+{
+    return ctx->hcode.nbr <= lf_decode4_rm_layers() && !(ctx->hcfg.method == 2 && ctx->hcfg.ef == 2);
+}
+static bool use_msg_registers(const lnsfaid_ctx* ctx)
+{
+    if (!msg_registers_possible(ctx)) return false;
+    return ctx->msg_store != LNSFAID_MSG_HBM;
+}
+
+static const void* selected_kernel(const lnsfaid_ctx* ctx, int* threads)
+{
+    if (use_kernel4(ctx)) {
+        *threads = lf_decode4_threads();
+        return lf_decode4_func(ctx->hcfg.method, ctx->hcfg.ef, use_msg_registers(ctx) ? 1 : 0);
+    }
+    *threads = lf_decode_threads();
+    return lf_decode_func(ctx->hcfg.method, ctx->hcfg.uniform_w);
+}
+
+extern "C" int lnsfaid_select_message_store(lnsfaid_ctx* ctx, int32_t where)
+{
+    if (!ctx || where < 0 || where > LNSFAID_MSG_HBM) return LNSFAID_E_INVAL;
+    if (where == LNSFAID_MSG_REGISTERS && !msg_registers_possible(ctx)) return LNSFAID_E_INVAL;
+    ctx->msg_store = where;
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_message_store(const lnsfaid_ctx* ctx)
+{
+    if (!ctx) return LNSFAID_E_INVAL;
+    if (!use_kernel4(ctx)) return LNSFAID_MSG_HBM; /* the two-rows kernel always streams them */
+    return use_msg_registers(ctx) ? LNSFAID_MSG_REGISTERS : LNSFAID_MSG_HBM;
+}
+
+/* Build-time properties of the kernel instance the context is about to launch, looked at once per instance:
+ *  - it must have no static LDS: the layer steps address En by its LDS offset, so the dynamic segment has to start at 0
+ *    (adding a __shared__ variable to a decode kernel would otherwise corrupt En silently);
+ *  - how many of its workgroups a CU holds.  The decoders are sized so that LDS alone decides that (50G-PON: 20 424 B per
+ *    codeword, 8 per CU); one more register or LDS word in the wrong place halves it, which costs ~40 % of the throughput and
+ *    nothing else would show.  Recorded for lnsfaid_kernel_residency, printed under LNSFAID_TRACE. */
+static const void* selected_kernel(const lnsfaid_ctx* ctx, int* threads);
+static int kernel_check(lnsfaid_ctx* ctx)
+{
+    int threads = 0;
+    const void* fn = selected_kernel(ctx, &threads);
+    if (!fn) return LNSFAID_E_INTERNAL;
+    if (fn == ctx->checked_fn) return LNSFAID_OK;
+    hipFuncAttributes at;
+    HIP_TRY(hipFuncGetAttributes(&at, fn));
+    if (at.sharedSizeBytes != 0) {
+        snprintf(g_hip_err, sizeof(g_hip_err), "decode kernel has %zu bytes of static LDS: its En image would not start at LDS offset 0",
+                 (size_t)at.sharedSizeBytes);
+        return LNSFAID_E_INTERNAL;
+    }
+    int wg = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg, fn, threads, ctx->lds_bytes));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    const size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 160 * 1024;
+    const size_t gran = 512; /* LDS allocation granularity */
+    int by_lds = (int)(lds_cu / ((ctx->lds_bytes + gran - 1) / gran * gran));
+    const int by_waves = 32 / ((threads + 63) / 64); /* 32 wave slots per CU */
+    if (by_lds > by_waves) by_lds = by_waves;
+    ctx->checked_fn = fn; ctx->resident_wg = wg; ctx->lds_wg = by_lds;
+    static const bool trace = getenv("LNSFAID_TRACE") != nullptr;
+    if (trace)
+        fprintf(stderr, "[lnsfaid] decode kernel: %d threads, %d VGPRs, %zu B LDS per workgroup, %d workgroups per CU (LDS alone: %d)%s\n",
+                threads, at.numRegs, ctx->lds_bytes, wg, by_lds, wg < by_lds ? "  ** residency lost **" : "");
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_kernel_residency(lnsfaid_ctx* ctx, int32_t* workgroups_per_cu, int32_t* lds_limit)
+{
+    if (!ctx) return LNSFAID_E_INVAL;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int rc = kernel_check(ctx);
+    if (rc) return rc;
+    if (workgroups_per_cu) *workgroups_per_cu = ctx->resident_wg;
+    if (lds_limit) *lds_limit = ctx->lds_wg;
+    return LNSFAID_OK;
+}
+
 extern "C" int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput, size_t n_groups, int8_t* d_decodedBits,
                                      lnsfaid_group_stats* d_stats)
 {
@@ -387,6 +482,10 @@ extern "C" int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput,
     if (n_groups > ctx->max_groups) return LNSFAID_E_INVAL;
     if (n_groups == 0) return LNSFAID_OK;
     HIP_TRY(hipSetDevice(ctx->device));
+    {
+        const int rc = kernel_check(ctx);
+        if (rc) return rc;
+    }
     const size_t n_cw = n_groups * LNSFAID_GROUP;
     HIP_TRY(hipMemsetAsync(ctx->d_status[0], 0, n_cw * sizeof(int32_t), ctx->stream)); /* every codeword fresh */
     HIP_TRY(hipMemsetAsync(ctx->d_live, 0, n_cw * sizeof(int32_t), ctx->stream));
@@ -407,7 +506,7 @@ extern "C" int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput,
         a.status_next = ctx->d_status[cur ^ 1];
         HIP_TRY(hipMemsetAsync(ctx->d_remaining, 0, sizeof(uint32_t), ctx->stream));
         HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-        if (use_kernel4(ctx)) HIP_TRY(lf_launch_decode4(ctx->hcfg.method, &a, ctx->lds_bytes, ctx->stream));
+        if (use_kernel4(ctx)) HIP_TRY(lf_launch_decode4(ctx->hcfg.method, ctx->hcfg.ef, use_msg_registers(ctx) ? 1 : 0, &a, ctx->lds_bytes, ctx->stream));
         else HIP_TRY(lf_launch_decode(ctx->hcfg.method, ctx->hcfg.uniform_w, &a, ctx->lds_bytes, ctx->stream));
         HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(hipMemcpyAsync(ctx->h_remaining, ctx->d_remaining, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -234,13 +234,39 @@ __device__ void build_erasure_plane4(CCode c, const LfDevCode* gc, uint32_t* pla
     __syncthreads();
 }
 
+/* ---- the compressed messages of the codeword on chip (RM instances) ------------------------------------------------
+ * A lane's four rows are 6 dwords per layer (SwRow), 72 per codeword for the 12 layers of the 50G-PON code: they stay in
+ * registers for the whole launch, field f of layer br in element br of vector f.  The layer number is wave-uniform, so an
+ * access is one v_mov_b32 under s_set_gpr_idx_on (no scratch, no waterfall).  Codes with more than LF4_RM_LAYERS layers
+ * stream the messages through HBM one layer ahead of use (the !RM instances). */
+#define LF4_RM_LAYERS 12
+static_assert(LF4_RM_LAYERS * 16 <= LF_SYN_ROUNDS * 64, "the RM instances assume that the syndrome walk tables fit the register cache");
+typedef uint32_t lf4_vec __attribute__((ext_vector_type(LF4_RM_LAYERS)));
+struct SwRegs {
+    lf4_vec x0, x1, x2, cw, pa0, pa1;
+};
+__device__ __forceinline__ SwRow regs_get(const SwRegs& R, int br)
+{
+    SwRow r;
+    r.x[0] = R.x0[br]; r.x[1] = R.x1[br]; r.x[2] = R.x2[br]; r.cw = R.cw[br]; r.pa[0] = R.pa0[br]; r.pa[1] = R.pa1[br];
+    return r;
+}
+__device__ __forceinline__ void regs_put(SwRegs& R, int br, const SwRow& r)
+{
+    R.x0[br] = r.x[0]; R.x1[br] = r.x[1]; R.x2[br] = r.x[2]; R.cw[br] = r.cw; R.pa0[br] = r.pa[0]; R.pa1[br] = r.pa[1];
+}
+
 /* ---- one layered iteration (lnsfaid_swar.h does the rows) ---- */
-template <int METHOD, bool ERA>
-__device__ __forceinline__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, const SwK& K, SwRow* __restrict__ rows, int lane, int it, const uint32_t* sP,
+template <int METHOD, bool ERA, bool RM>
+__device__ __forceinline__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, SwRow* __restrict__ rows, SwRegs& R, int lane, int it, const uint32_t* sP,
                            bool have_par, bool lme, uint32_t era_plane)
 {
+    /* register constants of the layer step: built per iteration (17 moves), outside the layer loop and the per-degree instances,
+     * and dead again before the syndrome stage - kept alive across it they are spilled (they come from asm statements, which
+     * the compiler cannot rematerialise) */
     it = __builtin_amdgcn_readfirstlane(it); /* uniform, and the compiler must know it: a divergent iteration number turns the
                                               * scalar branches and table loads of every layer into masked / per-lane ones */
+    const SwK K = sw_consts((uint32_t)it);
     const bool fresh = (it == 1); /* no iteration has run yet: every Lmn is still 0, nothing in HBM */
     const int rem = f->max_iter - it;
     const int itx = (it >= 1 && it <= 5) ? it - 1 : 5; /* switch at CDecoder_FAID.cpp:760-779 */
@@ -254,6 +280,37 @@ __device__ __forceinline__ void main_step4(CCode c, CCfg f, const LfDevCode* gc,
     const int nbr = c->nbr;
     const SwLds lds = SwLds();
     const SwRow zero = { { 0u, 0u, 0u }, 0u, { 0u, 0u } }; /* Lmn = 0 before the first iteration (CDecoder_FAID.cpp:211-214) */
+    if (RM) {
+        /* messages in registers: no vector memory operation inside the layer loop (the registers hold zeros before the first
+         * iteration: the kernel clears them when it stages a fresh codeword) */
+        uint32_t tabv = gc->sbplain[0][lane & 31];
+#pragma nounroll
+        for (int br = 0; br < nbr; ++br) {
+            const int brn = br + 1 < nbr ? br + 1 : 0;
+            const uint32_t tabn = gc->sbplain[brn][lane & 31]; /* next layer's edge table, a layer ahead of its use */
+            const int deg = c->deg[br];
+            uint32_t rowpar = 0;
+            if (have_par) { /* syndrome bits of rows lane + 64 k of this layer as byte masks */
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t wv = sP[br * 8 + 2 * k + (lane >> 5)];
+                    rowpar |= ((wv >> (lane & 31)) & 1u) ? (0xffu << (8 * k)) : 0u;
+                }
+            }
+            DevTab4 tab;
+            tab.c = c; tab.br = br; tab.sbv = tabv;
+            const SwRow cur = regs_get(R, br);
+            SwRow st;
+            const uint32_t era_edges = ERA ? c->era_edges[br] : 0u;
+            if (ERA) st = sw_layer_step<METHOD, 0, ERA>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme, era_edges, era_plane); /* rare: one instance */
+            else if (deg == 23) st = sw_layer_step<METHOD, 23>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
+            else if (deg == 22) st = sw_layer_step<METHOD, 22>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
+            else st = sw_layer_step<METHOD, 0>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
+            regs_put(R, br, st);
+            tabv = tabn;
+        }
+        return;
+    }
     SwRow cur = zero;
     if (!fresh) cur = rows[lane];
     uint32_t tabv = gc->sbplain[0][lane & 31];
@@ -290,16 +347,34 @@ __device__ __forceinline__ void main_step4(CCode c, CCfg f, const LfDevCode* gc,
         tabv = tabn;
         asm volatile("" : "+v"(cur.x[0]), "+v"(cur.x[1]), "+v"(cur.x[2]), "+v"(cur.cw), "+v"(cur.pa[0]), "+v"(cur.pa[1]), "+v"(tabv));
         __builtin_amdgcn_sched_barrier(0);
-#ifndef LF4_EXP_NO_ROWSTORE /* timing experiment only */
         if (rem > 0) rows[br * LF_T4 + lane] = st; /* the last layered iteration's messages are never read again */
-#else
-        asm volatile("" :: "v"(st.x[0]), "v"(st.x[1]), "v"(st.x[2]), "v"(st.cw), "v"(st.pa[0]), "v"(st.pa[1]));
-#endif
     }
 }
 
+/* messages of a parking / resuming codeword between the registers and its slot in HBM (RM instances): every layer's transfer
+ * in flight together (layers beyond the last one repeat it: no branches between the loads) */
+__device__ __forceinline__ void regs_store(const SwRegs& R, SwRow* __restrict__ rows, int nbr, int lane)
+{
+#pragma unroll
+    for (int br = 0; br < LF4_RM_LAYERS; ++br)
+        if (br < nbr) rows[br * LF_T4 + lane] = regs_get(R, br);
+}
+__device__ __forceinline__ void regs_load(SwRegs& R, const SwRow* __restrict__ rows, int nbr, int lane)
+{
+    SwRow r[LF4_RM_LAYERS];
+#pragma unroll
+    for (int br = 0; br < LF4_RM_LAYERS; ++br) r[br] = rows[(br < nbr ? br : nbr - 1) * LF_T4 + lane];
+#pragma unroll
+    for (int br = 0; br < LF4_RM_LAYERS; ++br) regs_put(R, br, r[br]);
+}
+__device__ __forceinline__ void regs_clear(SwRegs& R)
+{
+    const lf4_vec z = (lf4_vec)(0u);
+    R.x0 = z; R.x1 = z; R.x2 = z; R.cw = z; R.pa0 = z; R.pa1 = z;
+}
+
 /* ---- the decode kernel: one wave per codeword ---------------------------------------------------------- */
-template <int METHOD>
+template <int METHOD, bool RM, bool EF2>
 __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -308,11 +383,8 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
     const int tid = (int)threadIdx.x;
     const int cw = (int)blockIdx.x;
     const int N = c->n_var, M = c->n_check, K = c->k_info, nw = c->n_words, pw = c->p_words;
-    {   /* the layer step addresses En by its LDS offset: the dynamic segment must start at 0 */
-        uint32_t en_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-        asm volatile("" : "+s"(en_base));
-        if (en_base != 0u) __builtin_trap();
-    }
+    /* (the layer step addresses En by its LDS offset: the dynamic segment must start at 0, i.e. the kernel must have no static
+     * LDS - checked on the host when a context picks its kernel, lnsfaid_capi.hip kernel_check) */
     uint32_t* sHard0 = (uint32_t*)smem;      /* bit-flipping stage: hard_ch and hard2 overlay the dead En */
     uint32_t* sHard2 = (uint32_t*)smem + nw;
     uint32_t* sHard = (uint32_t*)(smem + lf_lds_off_hard(N));
@@ -376,6 +448,8 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
 
     bool in_bf = max_bf > 0 && prog >= t_bf0 && prog != 0;
     LfLaneState ls = { 0, 0, 0, 0 };
+    SwRegs R; /* RM: the codeword's compressed messages (dead in the bit-flipping stage) */
+    if (RM) regs_clear(R);
 
     /* ---- bring the codeword's state on chip ---- */
     if (prog == 0) {
@@ -436,6 +510,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
         prog = 1;
     } else if (!in_bf) {
         copy_in<23>((uint32_t*)smem, g_en, N >> 2, tid);
+        if (RM && prog >= 2) regs_load(R, g_rows, c->nbr, tid); /* parked in front of iteration 1: every Lmn is still 0 */
         __syncthreads();
     } else {
         copy_in<9>(sHard, g_bits, nw, tid);
@@ -445,12 +520,16 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
         __syncthreads();
     }
 
-    const SwK swk = sw_consts();
     bool parked = false;
     uint32_t pA = 0, pB = 0;
     /* ---- layered iterations (the syndrome stage in front of iteration prog is decision point prog) ---- */
     if (!in_bf) {
         while (prog < t_end && !(max_bf > 0 && prog >= t_bf0)) {
+            /* the lane number as this iteration sees it: opaque, so that the per-lane addresses and masks of the syndrome stage and
+             * the plane build are recomputed per iteration (a few dozen operations) instead of being hoisted out of the loop and
+             * kept alive - spilled, with the messages in registers - through every layer */
+            int tid_i = tid;
+            asm volatile("" : "+v"(tid_i));
             bool lme = false, have_par = false;
             /* l_checksum_ and the unsatisfied count are consumed only inside the error-floor window
              * (nombre_iterations <= floor_iter_thresh: OMS selective offset CDecoder_OMS.cpp:388, 2B1C tables
@@ -459,29 +538,35 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
             /* behind the group's front (the snapshot shows a lane parked beyond this point) the group is known to go on, and
              * outside the window nothing else reads the syndrome: a catching-up codeword skips the stage altogether */
             const bool must_know = needs_checksums || prog >= kmax;
-            if (must_know && (needs_checksums || !layer0_dirty4(c, tid))) {
-                build_plane4<false>(c, sHard, 0, tid);
+            if (must_know && (needs_checksums || !layer0_dirty4(c, tid_i))) {
+                build_plane4<false>(c, sHard, 0, tid_i);
                 int unsat;
-                if (syn_cache_fits(c->nbr)) { /* all table entries of the walk loaded together: one memory round trip, not one per round */
+                if (RM || syn_cache_fits(c->nbr)) { /* (RM: a code of up to LF4_RM_LAYERS layers always fits) all table entries of the walk loaded together: one memory round trip, not one per round */
                     SynCache sc;
-                    syn_cache_load(a.code, c->nbr, tid, sc);
-                    unsat = syndrome<LF_T4, false, true>(c, a.code, sP, tid, pA, pB, sRed, &sc);
+                    syn_cache_load(a.code, c->nbr, tid_i, sc);
+                    unsat = syndrome<LF_T4, false, true>(c, a.code, sP, tid_i, pA, pB, sRed, &sc);
                 } else {
-                    unsat = syndrome<LF_T4, false>(c, a.code, sP, tid, pA, pB, sRed);
+                    unsat = syndrome<LF_T4, false>(c, a.code, sP, tid_i, pA, pB, sRed);
                 }
                 /* clean on the group's front: park, unless a group mate is known to have passed this point */
-                if (unsat == 0 && prog >= kmax && !group_passed(a.live, g, prog, tid)) { parked = true; break; }
+                if (unsat == 0 && prog >= kmax && !group_passed(a.live, g, prog, tid_i)) {
+                    /* the messages leave the registers here, not in the common epilogue: there the compiler would have to keep
+                     * them alive through the whole bit-flipping stage */
+                    if (RM && prog >= 2) regs_store(R, g_rows, c->nbr, tid_i);
+                    parked = true;
+                    break;
+                }
                 if (LF4_OMS(METHOD)) lme = imin(unsat, 255) < (int)(uint8_t)f->floor_err_count; /* CDecoder_OMS.cpp:328 */
                 else lme = imin(unsat, 127) < (int)(int8_t)f->floor_err_count;              /* CDecoder_FAID.cpp:619 */
                 have_par = true;
             }
-            publish_pass(a.live, cw, prog, tid);
-            if (METHOD == 2 && f->ef == 2 && needs_checksums && have_par && lme) {
+            publish_pass(a.live, cw, prog, tid_i);
+            if (EF2 && f->ef == 2 && needs_checksums && have_par && lme) {
                 /* EF_ELIMINATION 2 inside the window, few unsatisfied checks: this iteration erases (CDecoder_FAID.cpp:673-680) */
-                build_erasure_plane4(c, a.code, sHard, sP, f->W, tid);
-                main_step4<METHOD, METHOD == 2>(c, f, a.code, swk, g_rows, tid, prog, sP, true, lme, lf_lds_off_hard(N));
+                build_erasure_plane4(c, a.code, sHard, sP, f->W, tid_i);
+                main_step4<METHOD, EF2, RM>(c, f, a.code, g_rows, R, tid_i, prog, sP, true, lme, lf_lds_off_hard(N));
             } else {
-                main_step4<METHOD, false>(c, f, a.code, swk, g_rows, tid, prog, sP, have_par && needs_checksums, lme, 0u);
+                main_step4<METHOD, false, RM>(c, f, a.code, g_rows, R, tid_i, prog, sP, have_par && needs_checksums, lme, 0u);
             }
             prog++;
         }
@@ -509,7 +594,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
     /* ---- bit-flipping iterations.  Nothing of the layer step is alive here, so the lanes keep their entries of the walk
      * tables in registers for the whole stage (no table load, hence no exposed memory latency, per iteration) ---- */
     if (in_bf && !parked) {
-        if (syn_cache_fits(c->nbr) && (METHOD == 3 || bf_cache_fits(c, f))) {
+        if ((RM || syn_cache_fits(c->nbr)) && (METHOD == 3 || bf_cache_fits(c, f))) {
             SynCache sc;
             BfCache bc;
             syn_cache_load(a.code, c->nbr, tid, sc);
@@ -552,7 +637,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
          * (the syndrome stage has just built the plane from this En; in the bit-flipping stage the plane is the state) as the
          * output for the case that it stops here */
         if (!in_bf) {
-            copy_out<23>(g_en, (const uint32_t*)smem, N >> 2, tid);
+            copy_out<23>(g_en, (const uint32_t*)smem, N >> 2, tid); /* (RM: the messages were stored where the codeword parked) */
         } else {
             copy_out<9>(g_bits, sHard, nw, tid);
             copy_out<9>(g_bits + nw, sHard0, nw, tid);
@@ -564,16 +649,28 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
     }
 }
 
-extern "C" hipError_t lf_launch_decode4(int method, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream)
+/* Instances: messages in registers (RM) for codes of up to LF4_RM_LAYERS layers, streamed through HBM otherwise; the erasing
+ * layer step of EF_ELIMINATION 2 (Decode_FAID only) lives in an instance of its own, so that the common ones do not carry its
+ * registers. */
+extern "C" int lf_decode4_rm_layers(void) { return LF4_RM_LAYERS; }
+
+/* the instance a configuration runs on (for hipFuncGetAttributes / the occupancy query, and for the launch) */
+extern "C" const void* lf_decode4_func(int method, int ef, int rm)
 {
-    const dim3 grid((unsigned)args->n_cw), block(LF_T4);
+    if (method == 2 && ef == 2) return (const void*)lnsfaid_decode4_kernel<2, false, true>;
+#define LF4_FUNC(M) case M: return rm ? (const void*)lnsfaid_decode4_kernel<M, true, false> : (const void*)lnsfaid_decode4_kernel<M, false, false>;
     switch (method) {
-    case 1: hipLaunchKernelGGL((lnsfaid_decode4_kernel<1>), grid, block, lds_bytes, stream, *args); break;
-    case 2: hipLaunchKernelGGL((lnsfaid_decode4_kernel<2>), grid, block, lds_bytes, stream, *args); break;
-    case 3: hipLaunchKernelGGL((lnsfaid_decode4_kernel<3>), grid, block, lds_bytes, stream, *args); break;
-    case 4: hipLaunchKernelGGL((lnsfaid_decode4_kernel<4>), grid, block, lds_bytes, stream, *args); break;
-    case 5: hipLaunchKernelGGL((lnsfaid_decode4_kernel<5>), grid, block, lds_bytes, stream, *args); break;
-    default: return hipErrorInvalidValue;
+        LF4_FUNC(1) LF4_FUNC(2) LF4_FUNC(3) LF4_FUNC(4) LF4_FUNC(5)
+    default: return nullptr;
     }
-    return hipGetLastError();
+#undef LF4_FUNC
+}
+extern "C" int lf_decode4_threads(void) { return LF_T4; }
+
+extern "C" hipError_t lf_launch_decode4(int method, int ef, int rm, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream)
+{
+    const void* fn = lf_decode4_func(method, ef, rm);
+    if (!fn) return hipErrorInvalidValue;
+    void* kargs[] = { (void*)args };
+    return hipLaunchKernel(fn, dim3((unsigned)args->n_cw), dim3(LF_T4), kargs, lds_bytes, stream);
 }

@@ -529,11 +529,8 @@ __global__ __launch_bounds__(LF_T, LF_WAVES_PER_SIMD) void lnsfaid_decode_kernel
     const int cw = (int)blockIdx.x;
     const int N = c->n_var, M = c->n_check, K = c->k_info, nw = c->n_words, pw = c->p_words;
     int8_t* sEn = (int8_t*)smem;
-    {   /* en_ld / en_st address En by its LDS offset: the dynamic segment must start at 0 */
-        uint32_t en_base = (uint32_t)(size_t)(lds_i8*)sEn;
-        asm volatile("" : "+s"(en_base)); /* link-time value: keep the compiler from assuming it */
-        if (en_base != 0u) __builtin_trap();
-    }
+    /* (en_ld / en_st address En by its LDS offset: the dynamic segment must start at 0, i.e. no static LDS in this kernel -
+     * checked on the host when a context picks its kernel, lnsfaid_capi.hip kernel_check) */
     uint32_t* sHard0 = (uint32_t*)smem;      /* bit-flipping stage: hard_ch and hard2 overlay the dead En */
     uint32_t* sHard2 = (uint32_t*)smem + nw;
     uint32_t* sHard = (uint32_t*)(smem + lf_lds_off_hard(N));
@@ -760,26 +757,33 @@ __global__ __launch_bounds__(256) void lnsfaid_count_errors_kernel(const int8_t*
 
 /* ---- launchers (called from lnsfaid_capi.hip) ---------------------------------------------------------- */
 template <int METHOD>
-static hipError_t launch_method(bool uniw, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream)
+static const void* func_method(bool uniw)
 {
-    const dim3 grid((unsigned)args->n_cw), block(LF_T);
-    if (uniw) hipLaunchKernelGGL((lnsfaid_decode_kernel<METHOD, true>), grid, block, lds_bytes, stream, *args);
-    else hipLaunchKernelGGL((lnsfaid_decode_kernel<METHOD, false>), grid, block, lds_bytes, stream, *args);
-    return hipGetLastError();
+    return uniw ? (const void*)lnsfaid_decode_kernel<METHOD, true> : (const void*)lnsfaid_decode_kernel<METHOD, false>;
 }
+
+/* the instance a configuration runs on (for hipFuncGetAttributes / the occupancy query, and for the launch) */
+extern "C" const void* lf_decode_func(int method, int uniform_w)
+{
+    switch (method) {
+    case 0: return func_method<0>(uniform_w != 0); /* normalised min-sum; uniform_w: Factor_1 == Factor_2 */
+    case 1: return func_method<1>(true); /* OMS has no look-up table */
+    case 2: return func_method<2>(uniform_w != 0);
+    case 3: return func_method<3>(true); /* OMS arithmetic + plain bit flipping */
+    case 4: return func_method<4>(true); /* OMS arithmetic + DTBF */
+    case 5: return func_method<5>(uniform_w != 0);
+    default: return nullptr;
+    }
+}
+extern "C" int lf_decode_threads(void) { return LF_T; }
 
 extern "C" hipError_t lf_launch_decode(int method, int uniform_w, const LfKernelArgs* args, size_t lds_bytes,
                                        hipStream_t stream)
 {
-    switch (method) {
-    case 0: return launch_method<0>(uniform_w != 0, args, lds_bytes, stream); /* normalised min-sum; uniform_w: Factor_1 == Factor_2 */
-    case 1: return launch_method<1>(true, args, lds_bytes, stream); /* OMS has no look-up table */
-    case 2: return launch_method<2>(uniform_w != 0, args, lds_bytes, stream);
-    case 3: return launch_method<3>(true, args, lds_bytes, stream); /* OMS arithmetic + plain bit flipping */
-    case 4: return launch_method<4>(true, args, lds_bytes, stream); /* OMS arithmetic + DTBF */
-    case 5: return launch_method<5>(uniform_w != 0, args, lds_bytes, stream);
-    default: return hipErrorInvalidValue;
-    }
+    const void* fn = lf_decode_func(method, uniform_w);
+    if (!fn) return hipErrorInvalidValue;
+    void* kargs[] = { (void*)args };
+    return hipLaunchKernel(fn, dim3((unsigned)args->n_cw), dim3(LF_T), kargs, lds_bytes, stream);
 }
 
 extern "C" hipError_t lf_launch_count_errors(const int8_t* decoded, const int8_t* input_bits, int n_var, int k_info,

@@ -95,12 +95,17 @@ __device__ __forceinline__ int syndrome(CCode c, const LfDevCode* gc, uint32_t* 
             const int ht = tid + 64 * r;
             if (ht < nbr * 16) {
                 uint32_t acc = 0;
+                /* all reads of the round in flight before the first use (left alone, a compiler short of registers pairs
+                 * "two reads, wait, combine": one LDS round trip per circulant) */
+                uint32_t w0[LF_SYN_JP], w1[LF_SYN_JP];
 #pragma unroll
                 for (int j = 0; j < LF_SYN_JP; ++j) {
                     const uint2 e = sc->e[r][j];
-                    const uint32_t w0 = *(lds_u32*)(size_t)(e.x & 0xffffu), w1 = *(lds_u32*)(size_t)(e.x >> 16);
-                    acc ^= __builtin_amdgcn_alignbit(w1, w0, e.y);
+                    w0[j] = *(lds_u32*)(size_t)(e.x & 0xffffu); w1[j] = *(lds_u32*)(size_t)(e.x >> 16);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < LF_SYN_JP; ++j) acc ^= __builtin_amdgcn_alignbit(w1[j], w0[j], sc->e[r][j].y);
                 acc ^= (uint32_t)__builtin_amdgcn_mov_dpp((int)acc, 0xb1, 0xf, 0xf, false); /* the other half of the circulant list */
                 if (!(ht & 1)) {
                     sP[ht >> 1] = acc;

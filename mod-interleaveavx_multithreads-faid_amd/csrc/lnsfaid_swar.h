@@ -117,13 +117,17 @@ SW_FN uint32_t sw_bitop3(uint32_t a, uint32_t b, uint32_t c)
 #define SW_TT_XNOR_AND 0x82 /* ~(a ^ b) & c        */
 
 /* a constant that must live in a VGPR (VOP3 takes no literal, and an SGPR operand halves the issue rate) */
-SW_FN uint32_t sw_vconst(uint32_t k)
+/* `dep`: any uniform value of the scope the constant belongs to.  The asm is not volatile, so the compiler hoists it out of every
+ * loop in which its inputs do not change: out of the layer loop, as wanted - and, without `dep`, out of the iteration loop too,
+ * across the syndrome stage, where the seventeen registers are then spilled (an asm result cannot be rematerialised). */
+SW_FN uint32_t sw_vconst(uint32_t k, uint32_t dep = 0u)
 {
 #if SW_DEV
     uint32_t r;
-    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(k)); /* not volatile: the compiler may hoist it out of the layer / iteration loops */
+    asm("v_mov_b32 %0, %1 ; %2" : "=v"(r) : "s"(k), "s"(dep));
     return r;
 #else
+    (void)dep;
     return k;
 #endif
 }
@@ -135,16 +139,16 @@ struct SwK {
     uint32_t cbit[8]; /* 0x01010101 << e; [0] = 0x01010101, [7] = 0x80808080 */
     uint32_t c7f;
 };
-SW_FN SwK sw_consts()
+SW_FN SwK sw_consts(uint32_t dep = 0u)
 {
     SwK k;
-    k.c78 = sw_vconst(0x78787878u); k.c0642 = sw_vconst(0x06040200u); k.cfc = sw_vconst(0xfcu);
-    k.sel_sign = sw_vconst(0x0b090a08u);
+    k.c78 = sw_vconst(0x78787878u, dep); k.c0642 = sw_vconst(0x06040200u, dep); k.cfc = sw_vconst(0xfcu, dep);
+    k.sel_sign = sw_vconst(0x0b090a08u, dep);
     /* thermometer code of min(|t|, 7); entry 7 equals what v_perm returns for a saturated selector */
-    k.tt_lo = sw_vconst(0x07030100u); k.tt_hi = sw_vconst(0xff3f1f0fu);
-    k.oh_lo = sw_vconst(0x08040201u); k.oh_hi = sw_vconst(0x80402010u);
-    for (int e = 0; e < 8; ++e) k.cbit[e] = sw_vconst(0x01010101u << e);
-    k.c7f = sw_vconst(0x7f7f7f7fu);
+    k.tt_lo = sw_vconst(0x07030100u, dep); k.tt_hi = sw_vconst(0xff3f1f0fu, dep);
+    k.oh_lo = sw_vconst(0x08040201u, dep); k.oh_hi = sw_vconst(0x80402010u, dep);
+    for (int e = 0; e < 8; ++e) k.cbit[e] = sw_vconst(0x01010101u << e, dep);
+    k.c7f = sw_vconst(0x7f7f7f7fu, dep);
     return k;
 }
 
@@ -463,7 +467,11 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
         else idx = sw_bitop3<SW_TT_ANDNOT_OR>(idx, ne, 0x01010101u << b);
     }
 
-    /* ---- the new arg-min edge: address, exact V2C, exact new En (its En in LDS is still the old value) ---- */
+    /* ---- the new arg-min edge: address, exact V2C, exact new En.  Its node address comes from the layer's edge table through
+     * ds_bpermute_b32 and its (still old) En from LDS: two dependent round trips, which nothing else of the wave would cover
+     * (two waves per SIMD).  Pass 2 does not depend on them, so its first group of edges is computed between the issue of
+     * the table look-up and its use, and the rest of it between the issue of the En reads and theirs.  LDS operations of a
+     * wave execute in order: the En reads are ISSUED before the first write of pass 2, so they return the old values. ---- */
     uint32_t pa[4], sbk[4], gb = 0, xb = 0;
     const uint32_t idx4 = idx << 2;
 #pragma unroll
@@ -472,6 +480,40 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
 #else
     for (int k = 0; k < 4; ++k) sbk[k] = tab.sb_dyn4((idx4 >> (8 * k)) & 0x7cu);
 #endif
+    SW_SCHED_FENCE();
+
+    /* ---- pass 2 (CDecoder_FAID.cpp:909-929, CDecoder_OMS.cpp:452-471): every edge as if it carried c2 ---- */
+    const SwUpd u2 = sw_update_consts<MINSUM>(c2n, fm, bias);
+    uint32_t ns[3] = { 0u, 0u, 0u };
+    uint32_t cbit[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cbit[e] = K.cbit[e];
+    /* one group of edges: the arithmetic (ARITH) and the LDS writes (STORE) separately, stage by stage over the group as in pass 1 */
+#define SW_PASS2_ARITH(J0, EN)                                                                                       \
+    {                                                                                                                \
+        const int j0 = (J0);                                                                                         \
+        uint32_t za[SW_ILP], sb[SW_ILP], oc[SW_ILP], hi[SW_ILP], mo[SW_ILP], mq[SW_ILP];                             \
+        SW_EDGES(za[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.za[1], u2.za[0]);)                                           \
+        SW_EDGES(sb[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.sb[1], u2.sb[0]);)                                           \
+        SW_EDGES(oc[g] = MINSUM ? sw_bitop3<SW_TT_SEL>(ms[j], u2.oc[1], u2.oc[0]) : u2.oc[1];)                       \
+        SW_EDGES(hi[g] = MINSUM ? sw_bitop3<SW_TT_SEL>(ms[j], u2.hi[1], u2.hi[0]) : u2.hi[1];)                       \
+        SW_EDGES(za[g] = tb[j] + za[g];)                 /* zb */                                                    \
+        SW_EDGES(oc[g] = za[g] - oc[g];)                                                                             \
+        SW_EDGES(mo[g] = sw_mask7(oc[g], sel_sign);)     /* over      */                                             \
+        SW_EDGES(mq[g] = sw_mask7(za[g], sel_sign);)     /* not under */                                             \
+        SW_EDGES(EN[g] = sw_bitop3<SW_TT_SEL>(mq[g], za[g], c80);)                                                   \
+        SW_EDGES(EN[g] = sw_bitop3<SW_TT_SEL>(mo[g], hi[g], EN[g]);)                                                 \
+        SW_EDGES(EN[g] = EN[g] - sb[g];)                                                                             \
+        SW_EDGES(EN[g] = sw_alignbyte(EN[g], EN[g], 4u - rq[j]);)                                                    \
+        SW_EDGES(ns[j >> 3] = sw_bitop3<SW_TT_ANDNOT_OR>(ns[j >> 3], ms[j], cbit[j & 7]);) /* bit e of byte k: V2C on edge 8 g + e not negative */ \
+    }
+#define SW_PASS2_STORE(J0, EN)                                                                                       \
+    {                                                                                                                \
+        const int j0 = (J0);                                                                                         \
+        SW_EDGES(lds.wr32(ad[j], EN[g]);)                                                                            \
+    }
+    uint32_t en0[SW_ILP], en1[SW_ILP];
+    SW_PASS2_ARITH(0, en0)
     SW_SCHED_FENCE();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -488,6 +530,10 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
         gb |= lds.rd8(pa[k]) << (8 * k);
 #endif
     }
+    SW_SCHED_FENCE();
+    SW_PASS2_STORE(0, en0)
+    if (SW_ILP < NJ) { SW_PASS2_ARITH(SW_ILP, en1) SW_PASS2_STORE(SW_ILP, en1) }
+    SW_SCHED_FENCE();
     /* the arg-min edges as one-hot bits inside their 8-edge word (byte k: 1 << (index mod 8)) and the word they are in
      * (index div 8 = 0, 1, 2) as byte masks, all four rows at once */
     const uint32_t oh8 = sw_perm(K.oh_hi, K.oh_lo, idx & 0x07070707u);
@@ -518,31 +564,15 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
     const SwUpd u1 = sw_update_consts<MINSUM, false>(c1n, 0u, bias);
     const uint32_t enA = sw_update<MINSUM>(tbA, ~negA, u1, sel_sign, c80);
 
-    /* ---- pass 2 (CDecoder_FAID.cpp:909-929, CDecoder_OMS.cpp:452-471): every edge as if it carried c2 ---- */
-    const SwUpd u2 = sw_update_consts<MINSUM>(c2n, fm, bias);
-    uint32_t ns[3] = { 0u, 0u, 0u };
-    uint32_t cbit[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) cbit[e] = K.cbit[e];
-#pragma unroll
-    for (int j0 = 0; j0 < NJ; j0 += SW_ILP) { /* stage by stage over groups of edges, as in pass 1 */
-        uint32_t za[SW_ILP], sb[SW_ILP], oc[SW_ILP], hi[SW_ILP], mo[SW_ILP], mq[SW_ILP], en[SW_ILP];
-        SW_EDGES(za[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.za[1], u2.za[0]);)
-        SW_EDGES(sb[g] = sw_bitop3<SW_TT_SEL>(ms[j], u2.sb[1], u2.sb[0]);)
-        SW_EDGES(oc[g] = MINSUM ? sw_bitop3<SW_TT_SEL>(ms[j], u2.oc[1], u2.oc[0]) : u2.oc[1];)
-        SW_EDGES(hi[g] = MINSUM ? sw_bitop3<SW_TT_SEL>(ms[j], u2.hi[1], u2.hi[0]) : u2.hi[1];)
-        SW_EDGES(za[g] = tb[j] + za[g];)                 /* zb */
-        SW_EDGES(oc[g] = za[g] - oc[g];)
-        SW_EDGES(mo[g] = sw_mask7(oc[g], sel_sign);)     /* over      */
-        SW_EDGES(mq[g] = sw_mask7(za[g], sel_sign);)     /* not under */
-        SW_EDGES(en[g] = sw_bitop3<SW_TT_SEL>(mq[g], za[g], c80);)
-        SW_EDGES(en[g] = sw_bitop3<SW_TT_SEL>(mo[g], hi[g], en[g]);)
-        SW_EDGES(en[g] = en[g] - sb[g];)
-        SW_EDGES(en[g] = sw_alignbyte(en[g], en[g], 4u - rq[j]);)
-        SW_EDGES(lds.wr32(ad[j], en[g]);)
-        SW_EDGES(ns[j >> 3] = sw_bitop3<SW_TT_ANDNOT_OR>(ns[j >> 3], ms[j], cbit[j & 7]);) /* bit e of byte k: V2C on edge 8 g + e not negative */
+    for (int jg = 2 * SW_ILP; jg < NJ; jg += SW_ILP) { /* the remaining groups of pass 2 */
+        uint32_t en[SW_ILP];
+        SW_PASS2_ARITH(jg, en)
+        SW_PASS2_STORE(jg, en)
     }
 #undef SW_EDGES
+#undef SW_PASS2_ARITH
+#undef SW_PASS2_STORE
     /* the arg-min edge carries c1: its exact En replaces the as-if value pass 2 wrote (same lane, LDS operations in order) */
 #ifndef SW_EXP_NO_ARGMIN
 #pragma unroll

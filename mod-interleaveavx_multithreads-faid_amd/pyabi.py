@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "liblnsfaid.so")
 
 GROUP = 32
+MSG_REGISTERS, MSG_HBM = 1, 2  # lnsfaid_select_message_store
 
 
 class Code(C.Structure):
@@ -86,6 +87,9 @@ SYMBOLS = {
     "lnsfaid_allreduce_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "lnsfaid_select_kernel": (C.c_int, [C.c_void_p, C.c_int32]),
     "lnsfaid_kernel_rows_per_lane": (C.c_int, [C.c_void_p]),
+    "lnsfaid_select_message_store": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lnsfaid_message_store": (C.c_int, [C.c_void_p]),
+    "lnsfaid_kernel_residency": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lnsfaid_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32]),
     "lnsfaid_stream": (C.c_void_p, [C.c_void_p]),
     "lnsfaid_strerror": (C.c_char_p, [C.c_int]),
@@ -212,6 +216,19 @@ class Decoder:
 
     def rows_per_lane(self):
         return self.lib.lnsfaid_kernel_rows_per_lane(self.ctx)
+
+    def select_message_store(self, where):
+        """0 default, MSG_REGISTERS, MSG_HBM (lnsfaid_select_message_store)"""
+        self._check(self.lib.lnsfaid_select_message_store(self.ctx, where), "lnsfaid_select_message_store")
+
+    def message_store(self):
+        return self.lib.lnsfaid_message_store(self.ctx)
+
+    def kernel_residency(self):
+        """(workgroups per CU of the selected kernel, what its LDS alone allows)"""
+        wg, lim = C.c_int32(), C.c_int32()
+        self._check(self.lib.lnsfaid_kernel_residency(self.ctx, C.byref(wg), C.byref(lim)), "lnsfaid_kernel_residency")
+        return wg.value, lim.value
 
     def kernel_time(self, reset=False):
         ms = C.c_double()

@@ -14,8 +14,12 @@ PKG_DIR = os.path.join(ROOT, "mod-interleaveavx_multithreads-faid_amd")
 
 def load_pyabi():
     """The package directory name is not a Python identifier, so import its ctypes module by path."""
+    import sys
+    if "lnsfaid_pyabi" in sys.modules:  # bench.py has loaded it already: one instance per process (ctypes classes compare by identity)
+        return sys.modules["lnsfaid_pyabi"]
     spec = importlib.util.spec_from_file_location("lnsfaid_pyabi", os.path.join(PKG_DIR, "pyabi.py"))
     mod = importlib.util.module_from_spec(spec)
+    sys.modules["lnsfaid_pyabi"] = mod
     spec.loader.exec_module(mod)
     return mod
 

@@ -145,6 +145,47 @@ def test_both_kernels_agree(abi, code50, method):
     assert np.array_equal(out2, ref) and np.array_equal(st2, ref_stats)
 
 
+@pytest.mark.parametrize("method", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("eb_n0", [3.55, 4.0])
+def test_messages_in_registers_and_streamed_through_hbm_agree(abi, code50, method, eb_n0):
+    """The four-rows kernel with the compressed messages in registers (default for the 12-layer code) and with the messages
+    streamed through HBM (the instance codes of more layers run on): identical frames and iteration counts, both equal to the
+    oracle.  The batch has groups whose codewords park and resume (clean lanes beside dirty ones), i.e. messages that travel
+    from the registers to HBM and back."""
+    cfg = abi.default_cfg(method, 10)
+    n = 6
+    fix = oa.ReferenceChannel(code50, 223, 13.0).groups(eb_n0, n)
+    ref, ref_stats = oa.Oracle(code50, cfg).decode(fix, n)
+    dec = abi.Decoder(code50, cfg, device=0, max_groups=n)
+    assert dec.rows_per_lane() == 4 and dec.message_store() == abi.MSG_REGISTERS
+    out_r, st_r = dec.decode(fix, n)
+    dec.select_message_store(abi.MSG_HBM)
+    assert dec.message_store() == abi.MSG_HBM
+    out_h, st_h = dec.decode(fix, n)
+    dec.select_message_store(0)
+    assert dec.message_store() == abi.MSG_REGISTERS
+    dec.close()
+    assert np.array_equal(out_r, ref) and np.array_equal(st_r, ref_stats)
+    assert np.array_equal(out_h, ref) and np.array_equal(st_h, ref_stats)
+    assert len({tuple(r) for r in ref_stats.tolist()}) > 1 or eb_n0 > 3.9  # mixed groups at the waterfall point
+
+
+def test_kernel_residency_is_what_the_lds_footprint_allows(abi, code50):
+    """Eight codewords per CU for the 50G-PON code, for every kernel instance a shipped configuration selects: a build that loses
+    residency to registers (or a static __shared__ in a decode kernel) fails here, not silently at 60 % of the throughput."""
+    for method in (0, 1, 2, 3, 4, 5):
+        dec = abi.Decoder(code50, abi.default_cfg(method, 10), device=0, max_groups=1)
+        wg, lim = dec.kernel_residency()
+        assert (wg, lim) == (8, 8), (method, dec.rows_per_lane(), wg, lim)
+        if dec.rows_per_lane() == 4:
+            for where in (abi.MSG_HBM, 0):
+                dec.select_message_store(where)
+                assert dec.kernel_residency() == (8, 8), (method, where)
+            dec.select_kernel(2)
+            assert dec.kernel_residency() == (8, 8), (method, "two rows per lane")
+        dec.close()
+
+
 def test_kernel_selection_rules(abi, code50):
     """NMS and tables that differ between weight classes stay on the two-rows-per-lane kernel; forcing the other is refused."""
     cfg = abi.default_cfg(0, 4)

@@ -42,13 +42,48 @@ def test_hot_path_has_no_function_calls(kernel4_asm):
     assert all("build_erasure_plane4" in f for f in funcs), funcs
     for name, body in kernel_bodies(kernel4_asm).items():
         calls = len(re.findall(r"s_swappc_b64", body))
-        assert calls <= (2 if "ILi2E" in name else 0), (name, calls)
+        assert calls <= (2 if "ILi2ELb0ELb1E" in name else 0), (name, calls)  # <2, RM = false, EF2 = true>
+
+
+def layer_loop_blocks(body):
+    """[(label, info, [instruction lines])] of the loop that holds the layer step (the largest depth-2 block and its loop mates)"""
+    blocks, cur = [], None
+    for line in body.split("\n"):
+        m = re.match(r"^(\.LBB\d+_\d+):\s*;?(.*)", line)
+        if m:
+            cur = [m.group(1), m.group(2), []]
+            blocks.append(cur)
+        elif cur is not None and re.match(r"^\s+;.*(Loop|Depth)", line):
+            cur[1] += " " + line.strip()
+        elif cur is not None and re.match(r"^\s+[a-z]", line):
+            cur[2].append(line.strip())
+    big = max((b for b in blocks if "Depth=2" in b[1]), key=lambda b: len(b[2]))
+    header = re.search(r"Header=(BB\d+_\d+)", big[1]).group(1)
+    return [b for b in blocks if "Depth=2" in b[1] and ("Header=" + header + " " in b[1] + " " or b[0] == ".L" + header)]
+
+
+def test_messages_in_registers_means_no_memory_traffic_in_the_layer_loop(kernel4_asm):
+    # RM instances <METHOD, true, false>: the compressed messages live in registers (indexed moves under s_set_gpr_idx_on), so the
+    # layer loop holds no global / scratch store and no load but the one-dword prefetch of the next layer's edge table
+    bodies = {n: b for n, b in kernel_bodies(kernel4_asm).items() if "Lb1ELb0E" in n}
+    assert len(bodies) == 5, sorted(bodies)
+    for name, body in bodies.items():
+        loop = layer_loop_blocks(body)
+        ops = [i for b in loop for i in b[2]]
+        assert sum(len(b[2]) for b in loop) > 1500, name  # the two per-degree instances of the layer step are in it
+        stores = [i for i in ops if re.match(r"(global|flat|buffer|scratch)_store", i)]
+        loads = [i for i in ops if re.match(r"(global|flat|buffer|scratch)_load", i)]
+        assert not stores, (name, stores)
+        assert len(loads) <= 1 and all(i.startswith("global_load_dword ") for i in loads), (name, loads)
+        assert any("s_set_gpr_idx_on" in i for i in ops), name
 
 
 def test_layer_loop_waits_for_no_memory_but_the_prefetch(kernel4_asm):
     # inside the layer loops (depth 2) vector memory is: prefetch of the next layer's messages at the top, one wait for it at the
     # bottom, the store of this layer's messages; a vmcnt wait anywhere else is a memory round trip per layer
     for name, body in kernel_bodies(kernel4_asm).items():
+        if "Lb1ELb0E" in name:
+            continue  # messages in registers: covered by the test above
         info, n = "", 0
         for line in body.split("\n"):
             m = re.match(r"^(\.LBB\d+_\d+):\s*;?(.*)", line)

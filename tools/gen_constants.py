@@ -6,14 +6,16 @@ from the built-in 50G-PON base matrix (csrc/lnsfaid_tables.c).  The output is a 
 
 usage: gen_constants.py <out_dir>
 """
+import importlib.util
 import os
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import oracle_abi as oa  # noqa: E402  (only for the path-based import of pyabi)
-
-pyabi = oa.pyabi
+# the package directory name is not a Python identifier: its ctypes module is imported by path (nothing from tests/ or oracle/)
+_spec = importlib.util.spec_from_file_location("lnsfaid_pyabi", os.path.join(ROOT, "mod-interleaveavx_multithreads-faid_amd", "pyabi.py"))
+pyabi = importlib.util.module_from_spec(_spec)
+sys.modules["lnsfaid_pyabi"] = pyabi
+_spec.loader.exec_module(pyabi)
 code = pyabi.Code50GPON(pyabi.load())
 out_dir = sys.argv[1]
 sub = os.path.join(out_dir, "50GPON-dc-original")
