@@ -14,8 +14,9 @@
  * One process per GPU: `--ranks N --rank r --comm-file F [--device d]` runs rank r of N cooperating processes.  The T streams
  * are cut into N contiguous ranges exactly like the G ranges above, every rank decodes its own range on its own GPU, and the
  * four counters are summed over RCCL after each round (lnsfaid_allreduce_counters: one 32-byte all-reduce), so every rank takes
- * the same stop decisions; rank 0 writes Result.txt.  The RCCL id travels through the file F (rank 0 writes it, the others
- * wait for it).
+ * the same stop decisions; rank 0 writes Result.txt.  The RCCL id travels through the file F (CommFile.h: rank 0 clears F,
+ * publishes the id under `--run-id ID`, removes F once every rank has joined; the others accept only a fresh record of the
+ * same run id and give up after `--comm-timeout S` seconds, exit code 3).
  */
 #include <sys/time.h>
 
@@ -31,6 +32,7 @@
 #include <vector>
 
 #include "CSimulate.h"
+#include "CommFile.h"
 
 using namespace std;
 
@@ -44,6 +46,9 @@ int main(int argc, char** argv)
     setenv("OMP_NUM_THREADS", "16", 0);
     int streams = 64, gpus = 1, max_rounds = 0, ranks = 1, rank = 0, device = -1;
     const char* comm_file = nullptr;
+    const char* run_id = "";
+    int comm_timeout_s = 120;
+    const int64_t started_at = (int64_t)time(nullptr);
     bool device_frontend = false, force_collect = false, encode = false;
     const char* profile = "Profile.txt";
     const char* resume = nullptr;
@@ -56,12 +61,14 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--rank") && i + 1 < argc) rank = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--comm-file") && i + 1 < argc) comm_file = argv[++i];
+        else if (!strcmp(argv[i], "--run-id") && i + 1 < argc) run_id = argv[++i]; /* the same on every rank of a run, new for every run */
+        else if (!strcmp(argv[i], "--comm-timeout") && i + 1 < argc) comm_timeout_s = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--max-rounds") && i + 1 < argc) max_rounds = atoi(argv[++i]); /* 0 = reference stop rule only */
         else if (!strcmp(argv[i], "--device-frontend")) device_frontend = true; /* channel + demapper + quantiser on the GPU */
         else if (!strcmp(argv[i], "--resume") && i + 1 < argc) resume = argv[++i]; /* lastSeed table of a Temp.txt (reference CONTINUE_SEED 1) */
         else if (!strcmp(argv[i], "--encode")) encode = true; /* random information bits + the encoder derived from H (reference FAKE_ENCODE 0) */
         else if (!strcmp(argv[i], "--collect")) force_collect = true; /* collectflag = 1 from the first call (reference: once FER < 1e-5) */
-        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R] [--device-frontend] [--encode] [--collect] [--resume Temp.txt] [--ranks N --rank r --comm-file F [--device d]]\n", argv[0]); return 2; }
+        else { fprintf(stderr, "usage: %s [--streams T] [--gpus G] [--profile Profile.txt] [--max-rounds R] [--device-frontend] [--encode] [--collect] [--resume Temp.txt] [--ranks N --rank r --comm-file F [--run-id ID] [--comm-timeout S] [--device d]]\n", argv[0]); return 2; }
     }
     if (streams < 1 || gpus < 1 || gpus > streams) { fprintf(stderr, "need 1 <= gpus <= streams\n"); return 2; }
     if (ranks < 1 || rank < 0 || rank >= ranks || (ranks > 1 && (gpus != 1 || !comm_file || ranks > streams))) {
@@ -90,23 +97,17 @@ int main(int argc, char** argv)
     }
     if (multi) { /* RCCL communicator of this run: the id travels through --comm-file */
         uint8_t id[LNSFAID_COMM_ID_BYTES];
+        static_assert(LNSFAID_COMM_ID_BYTES == COMMFILE_ID_BYTES, "CommFile.h carries one RCCL id");
         if (rank == 0) {
+            commfile_clear(comm_file); /* nothing of an earlier run may be found by a rank that starts after this point */
             if (lnsfaid_comm_unique_id(id)) { cerr << "RCCL is not available\n"; exit(EXIT_FAILURE); }
-            const string tmp = string(comm_file) + ".tmp";
-            ofstream f(tmp, ios::binary);
-            f.write((const char*)id, sizeof(id));
-            f.close();
-            rename(tmp.c_str(), comm_file);
-        } else {
-            bool got = false;
-            for (int tries = 0; tries < 1200 && !got; ++tries) { /* up to two minutes */
-                ifstream f(comm_file, ios::binary);
-                if (f.is_open() && f.read((char*)id, sizeof(id))) got = true;
-                else this_thread::sleep_for(chrono::milliseconds(100));
-            }
-            if (!got) { cerr << "no RCCL id in " << comm_file << "\n"; exit(EXIT_FAILURE); }
+            if (!commfile_publish(comm_file, run_id, id)) { cerr << "cannot write " << comm_file << "\n"; exit(EXIT_FAILURE); }
+        } else if (commfile_fetch(comm_file, run_id, id, comm_timeout_s * 1000, started_at)) {
+            cerr << "no RCCL id of run '" << run_id << "' in " << comm_file << " after " << comm_timeout_s << " s\n";
+            return 3;
         }
         simulate[0].ldpc->CommInit(p_simulation.decode_method, ranks, rank, id);
+        if (rank == 0) commfile_clear(comm_file); /* every rank has joined: the id must not outlive the run */
     }
 
     if (resume) {
@@ -145,6 +146,11 @@ int main(int argc, char** argv)
     fout << setw(5) << "Eb_N0" << '\t' << setw(20) << "TestFrame" << '\t' << setw(15) << "ErrorFrame" << '\t' << setw(20) << "ErrorBits"
          << '\t' << setw(20) << "FER" << '\t' << setw(20) << "BER" << '\t' << setw(15) << "LT3ErrBitFrame" << '\t' << setw(15) << "Time(s)" << '\t' << endl;
     fout.close();
+    if (rank == 0) { /* reference main.cpp:75-83 */
+        ofstream demodout("demod.txt", std::ios::app);
+        if (!demodout.is_open()) { cerr << "Cannot open demod.txt\n"; exit(EXIT_FAILURE); }
+        demodout << setw(5) << " Eb/N0" << '\t' << setw(20) << " ModFER" << '\t' << setw(20) << "ModBER" << '\t' << setw(20) << "ModSER" << '\t' << endl;
+    }
     if (rank == 0) cout << setw(5) << "Eb_N0" << setw(20) << "TestFrame" << setw(15) << "ErrorFrame" << setw(20) << "ErrorBits" << setw(20) << "FER"
          << setw(20) << "BER" << setw(15) << "LT3ErrBitFrame" << setw(15) << "Time(s)" << setw(18) << "decode info Gb/s" << endl;
 
@@ -196,6 +202,16 @@ int main(int argc, char** argv)
         fout << setw(5) << snr << '\t' << setw(20) << TestFrame << '\t' << setw(15) << ErrorFrame << '\t' << setw(20) << ErrorBits << '\t' << setw(20)
              << FER << '\t' << setw(20) << BER << '\t' << setw(15) << LT3ErrBitFrame << '\t' << setw(15) << total_time << '\t' << endl;
         fout.close();
+        if (rank == 0) {
+            /* reference main.cpp:183-186, :224-227: the demapper's own error rates.  The counters behind them are never
+             * incremented in the reference either (the ModCalErr call is commented out, CSimulate.cpp:129), so the row is zeros */
+            const unsigned long ModErrorBits = 0, ModErrorFrame = 0, ModErrorSymbol = 0;
+            const double ModBER = (double)ModErrorBits / ((double)TestFrame * (NmoinsK - _ShortenBits));
+            const double ModSER = (double)ModErrorSymbol / ((double)TestFrame * (NmoinsK - _ShortenBits) / p_simulation.mod_type);
+            const double ModFER = (double)ModErrorFrame / TestFrame;
+            ofstream demodout("demod.txt", std::ios::app);
+            demodout << setw(5) << snr << '\t' << setw(20) << ModFER << '\t' << setw(20) << ModBER << '\t' << setw(20) << ModSER << '\t' << endl;
+        }
     }
     return 0;
 }

@@ -24,8 +24,8 @@
  * golden vectors.  The oracle is pinned by (a) the reference's one known-answer fixture, the valid
  * codeword in Codeword.h:7-460, (b) the SHA-256 of PosNoeudsVariable, and (c) the error counters the
  * reference itself produced in this container during the survey (SURVEY.md §6 / BASELINE.md §2:
- * DecodeMethod x Eb/N0 x {frame errors, bit errors} for seed 101), which tests/test_oracle_anchor.py
- * reproduces through oracle/frontend_oracle.c (tests/test_oracle.py).  Those rows cover DecodeMethods 1, 2 and 5.
+ * DecodeMethod x Eb/N0 x {frame errors, bit errors} for seed 101), which tests/test_oracle.py
+ * reproduces through oracle/frontend_oracle.c.  Those rows cover DecodeMethods 1, 2 and 5.
  * DecodeMethods 0, 3 and 4: PARITY UNPINNED — no reference output was recorded for them; method 4 is the pinned OMS loop
  * followed by the pinned DTBF stage with other constants, methods 0 and 3 are statement-by-statement restatements
  * cross-checked only against the AVX2 port and the GPU.  See DESIGN.md "Oracle".

@@ -268,6 +268,11 @@ def test_host_driver_result_files(abi, code50, tmp_path, extra):
                     records.append((seed, g, i, bad, np.nonzero(d[g, i, code50.K:])[0] + code50.K, d[g, i]))
     lines = (tmp_path / "iterCount.txt").read_text().splitlines()
     assert lines[0].startswith("Eb/N0:")
+    # demod.txt (reference main.cpp:75-83, :224-227): header + one row per Eb/N0 point; its counters are never incremented in the
+    # reference either (CSimulate.cpp:129 is commented out), so the rates are zeros
+    demod = (tmp_path / "demod.txt").read_text().splitlines()
+    assert demod[0].split() == ["Eb/N0", "ModFER", "ModBER", "ModSER"] and len(demod) == 2
+    assert abs(float(demod[1].split()[0]) - eb_n0) < 1e-6 and [float(x) for x in demod[1].split()[1:]] == [0.0, 0.0, 0.0]
     got = {}
     for l in lines[1:]:
         k, v = l.split(":")
