@@ -253,8 +253,10 @@ int lnsfaid_allreduce_counters(lnsfaid_ctx* ctx, uint64_t counters[4]);
 
 /* Which decode kernel the context launches.  rows_per_lane 0 (default): chosen per configuration - the byte-parallel kernel
  * with four check rows per lane and one wavefront per codeword for DecodeMethods 1..5 with FAID tables that are uniform over
- * the weight classes and non-decreasing (every set the reference ships), the two-rows-per-lane kernel otherwise (NMS, other
- * tables); 2 / 4 force one of them (4: LNSFAID_E_INVAL where it does not apply).  Both produce identical results; the
+ * the weight classes and non-decreasing (every set the reference ships) and for DecodeMethod 0 with Factor_1 == Factor_2 in
+ * 15 .. 2114 (one normalisation factor whose scaled minimum has at most 16 levels), the two-rows-per-lane kernel otherwise
+ * (NMS with two factors or a factor outside that range, other tables); 2 / 4 force one of them (4: LNSFAID_E_INVAL where it does
+ * not apply).  Both produce identical results; the
  * switch exists for tests and A/B timing.  lnsfaid_kernel_rows_per_lane returns what the next decode will launch. */
 int lnsfaid_select_kernel(lnsfaid_ctx* ctx, int32_t rows_per_lane);
 int lnsfaid_kernel_rows_per_lane(const lnsfaid_ctx* ctx);
@@ -263,7 +265,7 @@ int lnsfaid_kernel_rows_per_lane(const lnsfaid_ctx* ctx);
  * lifetime CDecoder_FAID.cpp:211-214 ... :923) between the layers of a launch.  LNSFAID_MSG_REGISTERS: the compressed messages
  * of the codeword (72 dwords per lane for the 12 layers of the 50G-PON code) stay in the wavefront's registers for the whole
  * launch and reach HBM only when a codeword parks - no vector-memory operation inside the layer loop; available for codes of
- * up to 12 layers, not for EF_ELIMINATION 2.  LNSFAID_MSG_HBM: streamed through HBM one layer ahead of use (every code).
+ * up to 12 layers, not for EF_ELIMINATION 2 and not for DecodeMethod 0.  LNSFAID_MSG_HBM: streamed through HBM one layer ahead of use (every code).
  * 0 (default): registers where available.  Identical results either way; the switch exists for tests and A/B timing.
  * lnsfaid_message_store returns what the next decode will use. */
 #define LNSFAID_MSG_REGISTERS 1

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "lnsfaid_device.h"
+#include "lnsfaid_swar.h" /* sw_nms_fits / sw_nms_tables (host side) */
 
 extern "C" hipError_t lf_launch_decode(int method, int uniform_w, const LfKernelArgs* args, size_t lds_bytes,
                                        hipStream_t stream);
@@ -33,7 +34,22 @@ extern "C" hipError_t lf_launch_frontend(const uint32_t* d_seeds, const unsigned
                                          float sigma_ch, float scale, const int8_t* d_codeword, const int8_t* d_frames, int n_var,
                                          int n_check, int interleave, int8_t* d_fix, hipStream_t stream);
 
+#include <atomic>
 static thread_local char g_hip_err[256] = "";
+/* Contexts alive in this process.  A host thread that waits for its stream by spinning (hipStreamSynchronize) is the
+ * lowest-latency choice for a few contexts, and the worst one for the reference's call shape - one context per worker thread,
+ * 64 of them (reference main.cpp:31-34, :164-172): the spinning threads then fight for the cores the HIP runtime itself needs.
+ * From LF_SPIN_CONTEXTS live contexts on, waits go through an event created with hipEventBlockingSync (the thread sleeps
+ * until the interrupt); LNSFAID_SYNC=spin / block overrides. */
+static std::atomic<int> g_live_contexts(0);
+#define LF_SPIN_CONTEXTS 4
+static bool sync_blocking()
+{
+    static const char* e = getenv("LNSFAID_SYNC");
+    if (e && e[0] == 's') return false;
+    if (e && e[0] == 'b') return true;
+    return g_live_contexts.load(std::memory_order_relaxed) > LF_SPIN_CONTEXTS;
+}
 
 static int hip_fail(hipError_t e, const char* what)
 {
@@ -47,6 +63,7 @@ static int hip_fail(hipError_t e, const char* what)
     } while (0)
 
 #define LF_IO_CHUNKS 8 /* pieces the host-pointer path is cut into when both host buffers are pinned */
+#define LF_MAX_CHAIN 6 /* decode launches queued back to back before the host looks at their "codewords left" counters */
 
 struct lnsfaid_ctx {
     int device = 0;
@@ -57,6 +74,10 @@ struct lnsfaid_ctx {
     size_t lds_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_chain[LF_MAX_CHAIN + 1] = {}; /* time stamps around the launches of a chain */
+    hipEvent_t ev_block = nullptr;              /* hipEventBlockingSync: where the host waits when many contexts are alive */
+    uint32_t slot_seen[LF_MAX_CHAIN] = {};      /* last value read of each running "codewords left" counter */
+    int predicted_launches = 1;                 /* launches the previous batch needed: how many this one queues at once */
     hipStream_t s_in = nullptr, s_out = nullptr; /* copy streams of the pipelined host-pointer path */
     hipEvent_t ev_in[LF_IO_CHUNKS] = {};
     LfDevCode* d_code = nullptr;
@@ -69,7 +90,7 @@ struct lnsfaid_ctx {
     uint32_t* d_remaining = nullptr;
     int32_t* d_live = nullptr;
     unsigned long long* d_counters = nullptr;
-    uint32_t* h_remaining = nullptr;          /* pinned */
+    uint32_t* h_remaining = nullptr;          /* pinned, LF_MAX_CHAIN words */
     unsigned long long* h_counters = nullptr; /* pinned */
     /* staging for the host-pointer entry points */
     int8_t* d_io_in = nullptr;
@@ -93,6 +114,18 @@ struct lnsfaid_ctx {
     size_t fe_frames_streams = 0;  /* 0: frames not in use */
     int fe_interleave = 1;         /* InterleaveModType of the device front-end */
 };
+
+/* wait until everything queued on the context's stream so far has finished */
+static int stream_wait(lnsfaid_ctx* ctx)
+{
+    if (sync_blocking()) {
+        HIP_TRY(hipEventRecord(ctx->ev_block, ctx->stream));
+        HIP_TRY(hipEventSynchronize(ctx->ev_block));
+    } else {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return LNSFAID_OK;
+}
 
 /* ---- code analysis: PosNoeudsVariable -> circulants ------------------------------------------------- */
 static int weight_class(int w) { return w == 3 ? 0 : (w == 6 ? 1 : (w == 11 ? 2 : 3)); } /* CDecoder_FAID.cpp:692-705 */
@@ -239,7 +272,11 @@ static int build_cfg(const lnsfaid_cfg* cfg, LfDevCfg* out)
                 && (out->lut_ef_lo[it][w] != out->lut_ef_lo[it][0] || out->lut_ef_hi[it][w] != out->lut_ef_hi[it][0]))
                 out->uniform_w = 0;
         }
-    if (cfg->decode_method == 0) out->uniform_w = (out->factor_1 == out->factor_2) ? 1 : 0; /* NMS: one factor -> patch path */
+    if (cfg->decode_method == 0) {
+        out->uniform_w = (out->factor_1 == out->factor_2) ? 1 : 0; /* NMS: one factor -> patch path */
+        out->nms_fits = sw_nms_fits(out->factor_1, out->factor_2) ? 1 : 0;
+        if (out->nms_fits) sw_nms_tables(out->factor_1, out->nms_t);
+    }
     /* Decode_FAID with EF_ELIMINATION 1 / 2 exists in the four-rows-per-lane kernel only, which needs uniform tables */
     if (cfg->decode_method == 2 && cfg->ef_elimination >= 1 && !out->uniform_w) return LNSFAID_E_INVAL;
     out->bf_fast = (out->W == 3 && ((int8_t)out->alpha == 0 || (int8_t)out->alpha == 1)) ? 1 : 0;
@@ -261,6 +298,7 @@ extern "C" int lnsfaid_comm_destroy(lnsfaid_ctx* ctx);
 extern "C" void lnsfaid_destroy(lnsfaid_ctx* ctx)
 {
     if (!ctx) return;
+    g_live_contexts.fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     (void)lnsfaid_comm_destroy(ctx);
@@ -275,6 +313,8 @@ extern "C" void lnsfaid_destroy(lnsfaid_ctx* ctx)
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto e : ctx->ev_chain) if (e) (void)hipEventDestroy(e);
+    if (ctx->ev_block) (void)hipEventDestroy(ctx->ev_block);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
     if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
@@ -313,10 +353,13 @@ static int create_impl(lnsfaid_ctx* ctx, const lnsfaid_code* code, const lnsfaid
     HIP_TRY(hipMalloc(&ctx->d_lane, n_cw * sizeof(LfLaneState)));
     HIP_TRY(hipMalloc(&ctx->d_status[0], n_cw * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&ctx->d_status[1], n_cw * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&ctx->d_remaining, sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_remaining, LF_MAX_CHAIN * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(ctx->d_remaining, 0, LF_MAX_CHAIN * sizeof(uint32_t)));
+    for (auto& e : ctx->ev_chain) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_block, hipEventBlockingSync | hipEventDisableTiming));
     HIP_TRY(hipMalloc(&ctx->d_live, n_cw * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&ctx->d_counters, 4 * sizeof(unsigned long long)));
-    HIP_TRY(hipHostMalloc((void**)&ctx->h_remaining, sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&ctx->h_remaining, LF_MAX_CHAIN * sizeof(uint32_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault));
     HIP_TRY(hipMemcpy(ctx->d_code, &ctx->hcode, sizeof(LfDevCode), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_cfg, &ctx->hcfg, sizeof(LfDevCfg), hipMemcpyHostToDevice));
@@ -336,6 +379,7 @@ extern "C" int lnsfaid_create(lnsfaid_ctx** out, const lnsfaid_code* code, const
         ctx->rows_per_lane = (e[0] == '2') ? 2 : 0;
     if (const char* e = getenv("LNSFAID_MSG_STORE")) /* test / A-B switch, see lnsfaid_select_message_store */
         ctx->msg_store = (e[0] == 'h') ? LNSFAID_MSG_HBM : ((e[0] == 'r') ? LNSFAID_MSG_REGISTERS : 0);
+    g_live_contexts.fetch_add(1, std::memory_order_relaxed); /* (lnsfaid_destroy takes it back) */
     const int rc = create_impl(ctx, code, cfg);
     if (rc) { lnsfaid_destroy(ctx); return rc; }
     *out = ctx;
@@ -363,12 +407,13 @@ extern "C" int lnsfaid_set_cfg(lnsfaid_ctx* ctx, const lnsfaid_cfg* cfg)
 
 /* ---- the hot path ------------------------------------------------------------------------------------ */
 /* The four-rows-per-lane kernel (lnsfaid_kernel4.hip) covers DecodeMethods 1..5 with FAID tables that are uniform over the
- * weight classes and non-decreasing (OMS has no table) and needs max degree <= 24 like the other one; everything else, and
- * NMS, runs on the two-rows-per-lane kernel. */
+ * weight classes and non-decreasing (OMS has no table), and DecodeMethod 0 with Factor_1 == Factor_2 >= 15 (sw_nms_fits); it
+ * needs max degree <= 24 like the other one; everything else runs on the two-rows-per-lane kernel. */
 static bool kernel4_possible(const lnsfaid_ctx* ctx)
 {
     const int m = ctx->hcfg.method;
-    if (m < 1 || m > 5) return false;
+    if (m < 0 || m > 5) return false;
+    if (m == 0) return ctx->hcfg.nms_fits != 0; /* one factor, at most 16 levels (the usual normalisation factors) */
     if ((m == 2 || m == 5) && !ctx->hcfg.uniform_w) return false;
     return true;
 }
@@ -394,6 +439,7 @@ extern "C" int lnsfaid_kernel_rows_per_lane(const lnsfaid_ctx* ctx) { return ctx
  * lf_decode4_rm_layers() layers; not built for the erasing instance of EF_ELIMINATION 2) or streamed through HBM. */
 static bool msg_registers_possible(const lnsfaid_ctx* ctx)
 {
+    if (ctx->hcfg.method == 0) return false; /* NMS: the 16-level minimum search leaves no room for them */
     return ctx->hcode.nbr <= lf_decode4_rm_layers() && !(ctx->hcfg.method == 2 && ctx->hcfg.ef == 2);
 }
 static bool use_msg_registers(const lnsfaid_ctx* ctx)
@@ -487,39 +533,59 @@ extern "C" int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput,
         if (rc) return rc;
     }
     const size_t n_cw = n_groups * LNSFAID_GROUP;
-    HIP_TRY(hipMemsetAsync(ctx->d_status[0], 0, n_cw * sizeof(int32_t), ctx->stream)); /* every codeword fresh */
+#ifdef LF4_LIVE_PROOF /* experiment build only (lnsfaid_kernel4.hip publish_pass) */
     HIP_TRY(hipMemsetAsync(ctx->d_live, 0, n_cw * sizeof(int32_t), ctx->stream));
+#endif
 
     LfKernelArgs a;
     a.code = ctx->d_code; a.cfg = ctx->d_cfg;
     a.fix_input = d_fixInput; a.decoded = d_decodedBits;
     a.st_en = ctx->d_en; a.st_rows = ctx->d_rows; a.st_bits = ctx->d_bits; a.st_lane = ctx->d_lane;
-    a.remaining = ctx->d_remaining; a.live = ctx->d_live; a.stats = d_stats; a.n_cw = (int32_t)n_cw;
+    a.live = ctx->d_live; a.stats = d_stats; a.n_cw = (int32_t)n_cw;
 
-    /* every launch moves each unfinished group's front forward or finishes it; the time line has
-     * max_iter + max_bf + 1 points and a group needs at most two launches per point */
-    const long max_launches = 2L * ((long)ctx->hcfg.max_iter + ctx->hcfg.max_bf + 2) + 2;
+    /* Every launch moves each unfinished group's front forward or finishes it; the time line has max_iter + max_bf + 1
+     * points and a group needs at most two launches per point.  How many launches a batch takes is data dependent (one when
+     * nothing converges, three or four with early stop) and only known from the "codewords left" counter of the previous
+     * launch, so a host round trip per launch would sit between them - a quarter of the time of a one-group call.  Instead the
+     * launches the PREVIOUS batch needed are queued back to back (a launch on a finished batch is a grid of immediate exits,
+     * microseconds), their counters are read in one go, and only a batch that needs more continues one launch at a time.
+     * No memset in front: the first launch takes "every codeword fresh" from a null status pointer, and the counters are
+     * running sums of which the host remembers the last value it saw. */
+    const long max_launches = 2L * ((long)ctx->hcfg.max_iter + ctx->hcfg.max_bf + 2) + 2 + LF_MAX_CHAIN;
+    static const bool trace = getenv("LNSFAID_TRACE") != nullptr; /* read once: per-launch timing on stderr */
     int cur = 0;
-    for (long launch = 0;; ++launch) {
+    long launch = 0, needed = 0;
+    bool done = false;
+    while (!done) {
         if (launch >= max_launches) return LNSFAID_E_INTERNAL;
-        a.status_cur = ctx->d_status[cur];
-        a.status_next = ctx->d_status[cur ^ 1];
-        HIP_TRY(hipMemsetAsync(ctx->d_remaining, 0, sizeof(uint32_t), ctx->stream));
-        HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-        if (use_kernel4(ctx)) HIP_TRY(lf_launch_decode4(ctx->hcfg.method, ctx->hcfg.ef, use_msg_registers(ctx) ? 1 : 0, &a, ctx->lds_bytes, ctx->stream));
-        else HIP_TRY(lf_launch_decode(ctx->hcfg.method, ctx->hcfg.uniform_w, &a, ctx->lds_bytes, ctx->stream));
-        HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(ctx->h_remaining, ctx->d_remaining, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        ctx->kernel_ms += ms;
-        ctx->kernel_launches += 1;
-        static const bool trace = getenv("LNSFAID_TRACE") != nullptr; /* read once: per-launch timing on stderr */
-        if (trace) fprintf(stderr, "[lnsfaid] launch %ld: %.3f ms, %u codewords left\n", launch, ms, *ctx->h_remaining);
-        cur ^= 1;
-        if (*ctx->h_remaining == 0) break;
+        int chain = launch == 0 ? ctx->predicted_launches : 1;
+        if (chain < 1) chain = 1;
+        if (chain > LF_MAX_CHAIN) chain = LF_MAX_CHAIN;
+        for (int j = 0; j < chain; ++j) {
+            a.status_cur = (launch + j == 0) ? nullptr : ctx->d_status[cur];
+            a.status_next = ctx->d_status[cur ^ 1];
+            a.remaining = ctx->d_remaining + j;
+            HIP_TRY(hipEventRecord(ctx->ev_chain[j], ctx->stream));
+            if (use_kernel4(ctx)) HIP_TRY(lf_launch_decode4(ctx->hcfg.method, ctx->hcfg.ef, use_msg_registers(ctx) ? 1 : 0, &a, ctx->lds_bytes, ctx->stream));
+            else HIP_TRY(lf_launch_decode(ctx->hcfg.method, ctx->hcfg.uniform_w, &a, ctx->lds_bytes, ctx->stream));
+            cur ^= 1;
+        }
+        HIP_TRY(hipEventRecord(ctx->ev_chain[chain], ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_remaining, ctx->d_remaining, (size_t)chain * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        { const int rcw = stream_wait(ctx); if (rcw) return rcw; }
+        for (int j = 0; j < chain; ++j) {
+            const uint32_t left = ctx->h_remaining[j] - ctx->slot_seen[j]; /* running counter, modulo 2^32 */
+            ctx->slot_seen[j] = ctx->h_remaining[j];
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_chain[j], ctx->ev_chain[j + 1]));
+            ctx->kernel_ms += ms;
+            ctx->kernel_launches += 1;
+            if (trace) fprintf(stderr, "[lnsfaid] launch %ld: %.3f ms, %u codewords left%s\n", launch + j, ms, left, done ? " (queued ahead, batch already complete)" : "");
+            if (!done && left == 0) { done = true; needed = launch + j + 1; }
+        }
+        launch += chain;
     }
+    ctx->predicted_launches = (int)needed;
     return LNSFAID_OK;
 }
 
@@ -611,7 +677,7 @@ extern "C" int lnsfaid_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, size_t n
      * a piece is decoded to completion before the next one starts, so the pieces share the per-codeword state buffers).
      * Pageable buffers cannot overlap (the runtime stages them synchronously): one copy in, one decode, one copy out. */
     size_t chunk = ((n_groups + LF_IO_CHUNKS - 1) / LF_IO_CHUNKS + 63) / 64 * 64; /* >= one full wave of workgroups */
-    if (!host_pinned(fixInput) || !host_pinned(decodedBits) || chunk >= n_groups) {
+    if (chunk >= n_groups || !host_pinned(fixInput) || !host_pinned(decodedBits)) { /* (small batches: no pointer query at all) */
         HIP_TRY(hipMemcpyAsync(ctx->d_io_in, fixInput, bytes, hipMemcpyHostToDevice, ctx->stream));
         rc = lnsfaid_decode_device(ctx, ctx->d_io_in, n_groups, ctx->d_io_out, ctx->d_io_stats);
         if (rc) return rc;
@@ -641,7 +707,7 @@ extern "C" int lnsfaid_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, size_t n
     if (stats)
         HIP_TRY(hipMemcpyAsync(stats, ctx->d_io_stats, n_groups * sizeof(lnsfaid_group_stats), hipMemcpyDeviceToHost,
                                ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    { const int rcw = stream_wait(ctx); if (rcw) return rcw; }
     return LNSFAID_OK;
 }
 
@@ -671,7 +737,7 @@ extern "C" int lnsfaid_count_errors_device(lnsfaid_ctx* ctx, const int8_t* d_dec
                                    ctx->d_counters, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    { const int rcw = stream_wait(ctx); if (rcw) return rcw; }
     for (int i = 0; i < 4; ++i) out[i] += ctx->h_counters[i];
     return LNSFAID_OK;
 }
@@ -878,4 +944,11 @@ extern "C" const char* lnsfaid_strerror(int err)
 }
 
 extern "C" const char* lnsfaid_last_hip_error(void) { return g_hip_err; }
-extern "C" const char* lnsfaid_version(void) { return "lnsfaid-amd 0.1 (gfx950)"; }
+#ifndef LNSFAID_EXTRA_FLAGS
+#define LNSFAID_EXTRA_FLAGS ""
+#endif
+/* the experiment switches of the build (Makefile EXTRA) are part of the version: "lnsfaid-amd 0.3 (gfx950)" is the default build */
+extern "C" const char* lnsfaid_version(void)
+{
+    return sizeof(LNSFAID_EXTRA_FLAGS) > 1 ? "lnsfaid-amd 0.3 (gfx950) [" LNSFAID_EXTRA_FLAGS "]" : "lnsfaid-amd 0.3 (gfx950)";
+}

@@ -56,6 +56,9 @@ struct LfDevCfg {
     int32_t uniform_w; /* all four weight classes carry the same table rows and every row is non-decreasing (true for
                         * every shipped set): the table is then applied to the two minima instead of to every edge   */
     int32_t bf_fast;   /* W == 3 and alpha in {0, 1}: bit-sliced flip decision                                */
+    int32_t nms_fits;  /* DecodeMethod 0: one factor whose cste() has 16 levels at most (lnsfaid_swar.h sw_nms_fits): runs on the
+                        * four-rows-per-lane kernel with the table below                                                */
+    uint32_t nms_t[4]; /* thermometer codes of cste(0..15), 16 bytes                                                   */
     /* V2C_map_it{1..6}_[class] as 8 bytes for v_perm_b32: lo = entries 0..3, hi = entries 4..7 */
     uint32_t lut_lo[6][4], lut_hi[6][4];
     uint32_t lut_ef_lo[6][4], lut_ef_hi[6][4];
@@ -75,9 +78,9 @@ struct LfKernelArgs {
     uint4* st_rows;               /* [n_cw][nbr][128] compressed check-to-variable messages of a row pair  */
     uint32_t* st_bits;            /* [n_cw][3][n_words] hard / hard_ch / hard2 bit planes (BF stage)       */
     LfLaneState* st_lane;         /* [n_cw]                                                               */
-    const int32_t* status_cur;    /* [n_cw] decision point each codeword is parked at (snapshot)          */
+    const int32_t* status_cur;    /* [n_cw] decision point each codeword is parked at (snapshot); null = all 0 (first launch) */
     int32_t* status_next;         /* [n_cw] written by this launch                                        */
-    uint32_t* remaining;          /* number of codewords not finished after this launch                   */
+    uint32_t* remaining;          /* += number of codewords not finished after this launch (a running counter: never reset) */
     int32_t* live;                /* [n_cw] highest decision point each codeword has PASSED in this decode call, published
                                    * while the launch runs (four-rows-per-lane kernel); proof for group mates that the
                                    * group does not stop there */

@@ -14,7 +14,7 @@
  * stall: every loop that loads keeps all its loads in flight before the first use, the walk tables of the bit-flipping stage live in
  * registers, and everything on the hot path is inlined (tests/test_kernel_isa.py holds these properties).
  * Used for DecodeMethods 1..5 whenever the FAID tables are uniform over the weight classes and non-decreasing (every shipped
- * set); DecodeMethod 0 and other tables run on the two-rows-per-lane kernel.
+ * set) and for DecodeMethod 0 with one normalisation factor >= 15; other tables / factors run on the two-rows-per-lane kernel.
  */
 #include <hip/hip_runtime.h>
 
@@ -277,6 +277,7 @@ __device__ __forceinline__ void main_step4(CCode c, CCfg f, const LfDevCode* gc,
     p.window = rem <= f->floor_iter_thresh;
     p.ef_tables = f->ef >= 1;
     if (LF4_OMS(METHOD)) sw_oms_tables(p); /* uniform: scalar work, once per iteration */
+    if (METHOD == 0) { p.nms_t[0] = f->nms_t[0]; p.nms_t[1] = f->nms_t[1]; p.nms_t[2] = f->nms_t[2]; p.nms_t[3] = f->nms_t[3]; }
     const int nbr = c->nbr;
     const SwLds lds = SwLds();
     const SwRow zero = { { 0u, 0u, 0u }, 0u, { 0u, 0u } }; /* Lmn = 0 before the first iteration (CDecoder_FAID.cpp:211-214) */
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
     /* snapshot of the 32 lanes of this group: one load per lane (both halves of the wave hold the same 32 words), everything
      * else in registers - no LDS round trips in front of the early exits, which most workgroups of a relaunch take */
     const int g = cw >> 5, lane_in_group = cw & 31;
-    const int sv = a.status_cur[g * LNSFAID_GROUP + (tid & 31)];
+    const int sv = a.status_cur ? a.status_cur[g * LNSFAID_GROUP + (tid & 31)] : 0; /* null: first launch of a batch, every codeword fresh */
     const int my_status = __builtin_amdgcn_readlane(sv, lane_in_group);
     if (my_status & LF_DONE) { /* uniform exit */
         if (tid == 0) a.status_next[cw] = my_status;
@@ -530,6 +531,11 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
              * kept alive - spilled, with the messages in registers - through every layer */
             int tid_i = tid;
             asm volatile("" : "+v"(tid_i));
+            if (METHOD == 0) { /* CLDPC::Decode has no syndrome stage and no early stop (CLDPC.cpp:287-2283) */
+                main_step4<METHOD, false, RM>(c, f, a.code, g_rows, R, tid_i, prog, sP, false, false, 0u);
+                prog++;
+                continue;
+            }
             bool lme = false, have_par = false;
             /* l_checksum_ and the unsatisfied count are consumed only inside the error-floor window
              * (nombre_iterations <= floor_iter_thresh: OMS selective offset CDecoder_OMS.cpp:388, 2B1C tables
@@ -660,6 +666,7 @@ extern "C" const void* lf_decode4_func(int method, int ef, int rm)
     if (method == 2 && ef == 2) return (const void*)lnsfaid_decode4_kernel<2, false, true>;
 #define LF4_FUNC(M) case M: return rm ? (const void*)lnsfaid_decode4_kernel<M, true, false> : (const void*)lnsfaid_decode4_kernel<M, false, false>;
     switch (method) {
+    case 0: return (const void*)lnsfaid_decode4_kernel<0, false, false>; /* (16-level search: with the messages in registers too the layer step spills) */
         LF4_FUNC(1) LF4_FUNC(2) LF4_FUNC(3) LF4_FUNC(4) LF4_FUNC(5)
     default: return nullptr;
     }

@@ -542,14 +542,14 @@ __global__ __launch_bounds__(LF_T, LF_WAVES_PER_SIMD) void lnsfaid_decode_kernel
     const int t_bf0 = max_iter + 1;   /* first bit-flipping decision point */
     const int t_end = t_bf0 + max_bf; /* both loops exhausted               */
 
-    const int my_status = a.status_cur[cw];
+    const int my_status = a.status_cur ? a.status_cur[cw] : 0; /* null: first launch of a batch, every codeword fresh */
     if (my_status & LF_DONE) { /* uniform exit */
         if (tid == 0) a.status_next[cw] = my_status;
         return;
     }
     /* snapshot of the 32 lanes of this group */
     const int g = cw >> 5, lane_in_group = cw & 31;
-    if (tid < LNSFAID_GROUP) sStat[tid] = a.status_cur[g * LNSFAID_GROUP + tid];
+    if (tid < LNSFAID_GROUP) sStat[tid] = a.status_cur ? a.status_cur[g * LNSFAID_GROUP + tid] : 0;
     if (tid == LNSFAID_GROUP) sRed[LF_ZERO_SLOT] = 0; /* the word unused synw slots point at */
     __syncthreads();
     int kmax = 0, all_same = 1;

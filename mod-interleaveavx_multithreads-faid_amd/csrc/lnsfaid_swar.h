@@ -40,9 +40,11 @@
 #if defined(__HIPCC__) /* both passes of hipcc see the device flavour; a plain C++ compiler gets the restatements */
 #define SW_DEV 1
 #define SW_FN __device__ __forceinline__
+#define SW_HD __host__ __device__ __forceinline__ /* table builders: also run by the host side of the C ABI */
 #else
 #define SW_DEV 0
 #define SW_FN static inline
+#define SW_HD static inline
 #endif
 
 #define SW_MAX_DEG 24
@@ -138,6 +140,7 @@ struct SwK {
     uint32_t c78, c0642, cfc, sel_sign, tt_lo, tt_hi, oh_lo, oh_hi;
     uint32_t cbit[8]; /* 0x01010101 << e; [0] = 0x01010101, [7] = 0x80808080 */
     uint32_t c7f;
+    uint32_t c70;     /* NMS only: its minima keep 16 levels */
 };
 SW_FN SwK sw_consts(uint32_t dep = 0u)
 {
@@ -149,6 +152,7 @@ SW_FN SwK sw_consts(uint32_t dep = 0u)
     k.oh_lo = sw_vconst(0x08040201u, dep); k.oh_hi = sw_vconst(0x80402010u, dep);
     for (int e = 0; e < 8; ++e) k.cbit[e] = sw_vconst(0x01010101u << e, dep);
     k.c7f = sw_vconst(0x7f7f7f7fu, dep);
+    k.c70 = sw_vconst(0x70707070u, dep);
     return k;
 }
 
@@ -184,6 +188,8 @@ struct SwParams {
     int32_t f1, f2;                /* Factor_1 / Factor_2 (OMS offsets, NMS numerators)                          */
     int32_t window;                /* nombre_iterations <= floor_iter_thresh                                     */
     int32_t ef_tables;             /* EF_ELIMINATION >= 1 (always so for DecodeMethod 5; 0, 1 or 2 for DecodeMethod 2)  */
+    uint32_t nms_t[4];             /* NMS with one factor: thermometer code of cste(m) = min((m * Factor) >> 5, 7) for m = 0..15 as 16
+                                    * bytes (sw_nms_tables); m >= 16 saturates to 0xff, the code of 7                     */
     uint32_t oms_lo[2], oms_hi[2]; /* min-sum decoders: the selective offset + clamp as 8-entry byte tables over the minimum
                                     * (0..7), [0] the ordinary rule, [1] the rule of an unsatisfied row inside the window
                                     * (sw_oms_tables fills them from f1 / f2)                                         */
@@ -242,6 +248,38 @@ SW_FN void sw_oms_tables(SwParams& p)
             if (x < 4) lo |= v << (8 * x); else hi |= v << (8 * (x - 4));
         }
         p.oms_lo[r] = lo; p.oms_hi[r] = hi;
+    }
+}
+
+/* Normalised min-sum (CLDPC::Decode, CLDPC.cpp:337-352): cste(m) = min(pack_s8((uint16)(m * Factor) >> 5), 7) in 16-bit lanes
+ * (VECTOR_MUL = _mm256_mullo_epi16, VECTOR_DIV32 = _mm256_srli_epi16(.., 5), VECTOR_PACK = _mm256_packs_epi16), m = 0..31. */
+SW_HD int sw_nms_cste(int m, int factor)
+{
+    const uint16_t p = (uint16_t)((uint16_t)m * (uint16_t)(int16_t)factor);
+    const int16_t q = (int16_t)(p >> 5);
+    const int r = q > 127 ? 127 : q;
+    return r > 7 ? 7 : r;
+}
+/* The byte-parallel layer step applies a row's magnitude function to the LEVELS of the minimum search: with one factor for both
+ * minima cste() plays the part of the FAID table (a non-decreasing map commutes with the minimum, and edges that tie after the
+ * map get the same message whichever of them is called the arg-min - DESIGN.md 3.2).  The search keeps 16 levels of |t| (two
+ * v_perm_b32 tables), so cste() must be non-decreasing and have reached its end value 7 at m = 15: true for Factor >= 15 up to
+ * the 16-bit wrap (Factor <= 2114), i.e. for every normalisation factor in use (24 / 32 = 0.75 ...); other factors, and two
+ * different factors (a tie then gives the two minima different messages), stay on the two-rows-per-lane kernel. */
+SW_HD bool sw_nms_fits(int f1, int f2)
+{
+    if (f1 != f2) return false;
+    for (int m = 1; m < 32; ++m)
+        if (sw_nms_cste(m, f1) < sw_nms_cste(m - 1, f1)) return false;
+    return sw_nms_cste(15, f1) == 7;
+}
+SW_HD void sw_nms_tables(int factor, uint32_t nms_t[4])
+{
+    for (int w = 0; w < 4; ++w) nms_t[w] = 0;
+    for (int m = 0; m < 16; ++m) {
+        const int c = sw_nms_cste(m, factor);
+        const uint32_t code = c >= 7 ? 0xffu : ((1u << c) - 1u); /* bit i set iff c > i */
+        nms_t[m >> 2] |= code << (8 * (m & 3));
     }
 }
 
@@ -307,7 +345,7 @@ SW_FN uint32_t sw_plane_bit(const SwLds& lds, uint32_t era_plane, uint32_t a)
  * (block column * 256) << 16 | 4 * shift for a per-lane edge index.
  * rowpar: byte mask, 0xff in byte k if the syndrome bit of row i + 64 k is set (only read by the OMS selective offset
  * and the 2B1C error-floor tables); lme: unsat < floor_err_count for this codeword.
- * DecodeMethod 0 (NMS) is not built here: its minima run over |t| up to 31, more levels than the 8-entry thermometer holds. */
+ * DecodeMethod 0 (NMS, one factor): the minimum search keeps 16 levels of |t| and maps them through cste() (sw_nms_tables). */
 template <int METHOD, int DEG, bool ERA = false, class Tab>
 SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, const SwK& K, uint32_t lane, int deg, SwRow cur, bool fresh,
                           uint32_t rowpar, bool lme, uint32_t era_edges = 0u, uint32_t era_plane = 0u)
@@ -414,9 +452,22 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
          * (b = 0 for the min-sum decoders); 0x78 is added on top so that |t| >= 8 reaches bit 7, which the table look-up
          * turns into the saturated code */
         SW_EDGES(a_[g] = sw_bitop3<SW_TT_XOR3>(ts[j], c7f, ms[j]);)
-        SW_EDGES(i_[g] = MINSUM ? sw_bitop3<SW_TT_NANDOR>(ms[j], c01, c78) : sw_bitop3<SW_TT_XNOR_AND>(x_[g], ms[j], c01);)
-        SW_EDGES(a_[g] = (MINSUM ? a_[g] + i_[g] : a_[g] + i_[g] + c78) & 0x87878787u;)     /* v_add3_u32 */
-        SW_EDGES(u_[g] = sw_perm(tt_hi, tt_lo, a_[g]);)
+        if (METHOD == 0) {
+            /* NMS: 16 levels.  0x70 on top so that |t| >= 16 reaches bit 7 (both look-ups then return the saturated code); bit 3
+             * picks the table: entries 8..15 (nms_t[3], nms_t[2]) or 0..7 (nms_t[1], nms_t[0]) */
+            uint32_t h_[SW_ILP];
+            SW_EDGES(i_[g] = sw_bitop3<SW_TT_NANDOR>(ms[j], c01, K.c70);)
+            SW_EDGES(a_[g] = (a_[g] + i_[g]) & 0x8f8f8f8fu;)
+            SW_EDGES(h_[g] = sw_mask7(a_[g] << 4, sel_sign);)
+            SW_EDGES(a_[g] &= 0x87878787u;)
+            SW_EDGES(i_[g] = sw_perm(p.nms_t[3], p.nms_t[2], a_[g]);)
+            SW_EDGES(u_[g] = sw_perm(p.nms_t[1], p.nms_t[0], a_[g]);)
+            SW_EDGES(u_[g] = sw_bitop3<SW_TT_SEL>(h_[g], i_[g], u_[g]);)
+        } else {
+            SW_EDGES(i_[g] = MINSUM ? sw_bitop3<SW_TT_NANDOR>(ms[j], c01, c78) : sw_bitop3<SW_TT_XNOR_AND>(x_[g], ms[j], c01);)
+            SW_EDGES(a_[g] = (MINSUM ? a_[g] + i_[g] : a_[g] + i_[g] + c78) & 0x87878787u;)     /* v_add3_u32 */
+            SW_EDGES(u_[g] = sw_perm(tt_hi, tt_lo, a_[g]);)
+        }
         SW_EDGES(
             if (j & 1) sx = sw_bitop3<SW_TT_XOR3>(sx, ts[j - 1], ts[j]); else if (j == (DEG > 0 ? DEG : deg) - 1) sx ^= ts[j];
             t2 = sw_bitop3<SW_TT_A_AND_BORC>(t2, t1, u_[g]);      /* VECTOR_MIN_2 with the old min1 */
@@ -427,8 +478,11 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
     /* ---- the row's new magnitudes ---- */
     uint32_t min1 = sw_popcount7(t1), min2 = sw_popcount7(t2);
     uint32_t c1n, c2n;
-    static_assert(METHOD != 0, "NMS keeps |t| up to 31 in its minima: it runs on the two-rows-per-lane kernel");
-    if (SW_OMS(METHOD)) {
+    if (METHOD == 0) {
+        /* the levels of the search ARE cste() of the minima (CLDPC.cpp:337-352: cste_2 from min1, cste_1 from min2, one factor) */
+        c2n = min1;
+        c1n = min2;
+    } else if (SW_OMS(METHOD)) {
         /* selective offset and clamp (cste_2 from min1, cste_1 from min2, CDecoder_OMS.cpp:431-432) as table look-ups; rows
          * with an unsatisfied check take the other rule inside the error-floor window of a codeword with few of them (:388) */
         c2n = sw_perm(p.oms_hi[0], p.oms_lo[0], min1);

@@ -537,11 +537,12 @@ static void decode_group(lnsfaid_oracle* o, const int8_t* fixInput, int8_t* deco
  * (the syndrome stage still runs for l_checksum_ / l_m_error_sum), En of every lane returned as en_out[l * N + v]. */
 int lnsfaid_oracle_layered_en(lnsfaid_oracle* o, const int8_t* fixInput, int n_iter, int8_t* en_out)
 {
-    if (!o || !fixInput || !en_out || o->cfg.decode_method == 0) return LNSFAID_E_INVAL;
+    if (!o || !fixInput || !en_out) return LNSFAID_E_INVAL;
     const lnsfaid_cfg* c = &o->cfg;
     const int oms = (c->decode_method == 1 || c->decode_method == 3 || c->decode_method == 4);
     stage_input(o, fixInput);
     for (int it = 1; it <= n_iter; ++it) {
+        if (c->decode_method == 0) { nms_iteration(o); continue; } /* CLDPC::Decode: no syndrome stage */
         v32 error_sum = syndrome_stage(o, oms);
         m32 l_m_error_sum = oms ? m_ltu(error_sum, v_set1((uint8_t)c->floor_err_count)) : m_lt(error_sum, v_set1((int8_t)c->floor_err_count));
         layered_iteration(o, c->max_iteration - it, l_m_error_sum);

@@ -98,6 +98,11 @@ extern "C" int swar_emul_layered(const lnsfaid_code* code, const lnsfaid_cfg* cf
             p.window = rem <= cfg->floor_iter_thresh;
             p.ef_tables = cfg->ef_elimination >= 1;
             sw_oms_tables(p);
+            if (method == 0) {
+                if (!sw_nms_fits((int16_t)cfg->factor_1, (int16_t)cfg->factor_2)) return LNSFAID_E_INVAL; /* (the kernel would not run it) */
+                p.f1 = p.f2 = (int16_t)cfg->factor_1;
+                sw_nms_tables(p.f1, p.nms_t);
+            }
             /* EF_ELIMINATION 2: erase in this iteration?  plane bit v = all checks of v unsatisfied (weight-W columns) */
             const int W = cfg->regular_col_weight;
             const bool erase = method == 2 && cfg->ef_elimination == 2 && p.window && lme;
@@ -126,6 +131,7 @@ extern "C" int swar_emul_layered(const lnsfaid_code* code, const lnsfaid_cfg* cf
                     if (method == 2) cur = step<2>(deg[br], specialised != 0, lds, tab, p, lane, cur, fresh, rowpar, lme, erase, era_edges[br], plane_off);
                     else if (method == 5) cur = step<5>(deg[br], specialised != 0, lds, tab, p, lane, cur, fresh, rowpar, lme);
                     else if (oms) cur = step<1>(deg[br], specialised != 0, lds, tab, p, lane, cur, fresh, rowpar, lme);
+                    else if (method == 0) cur = step<0>(deg[br], specialised != 0, lds, tab, p, lane, cur, fresh, rowpar, lme);
                     else return LNSFAID_E_INVAL;
                 }
             }

@@ -98,6 +98,10 @@ def test_bench_two_ranks_through_the_hip_library():
         argv += ["--share-gpu", "--backend", "gloo"]
     d = _bench_line(argv)
     assert d["n_gpus"] == 2 and d["config"]["backend"] == ("nccl" if two else "gloo")
+    # one GPU per rank: the counters go through the PRODUCT's reduction (lnsfaid_comm_init + lnsfaid_allreduce_counters, RCCL);
+    # gloo only where two ranks share a device
+    assert d["config"]["reduce"] == ("lnsfaid_allreduce_counters" if two else "torch.distributed gloo")
+    assert len(d["config"]["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["config"]["per_rank_ms_per_step"])
     assert d["config"]["counters_TestFrame_ErrorFrame_ErrorBits_LT3"][0] == 2 * 64 * 32
     assert d["strong"]["counters_TestFrame_ErrorFrame_ErrorBits_LT3"][0] == 64 * 32
     assert d["value"] > 0 and d["roofline"]["launches"] >= 2
@@ -108,4 +112,5 @@ def test_bench_single_gpu_through_the_launcher():
     """N = 1 through the same spawn path the N > 1 runs take (RCCL world of one)."""
     d = _bench_line(["--gpus", "1", "--spawn", "--groups", "64", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-points"])
     assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl"
+    assert d["config"]["reduce"] == "lnsfaid_allreduce_counters"  # RCCL communicator of one rank, through the C ABI
     assert d["config"]["counters_TestFrame_ErrorFrame_ErrorBits_LT3"][0] == 64 * 32

@@ -41,6 +41,42 @@ def test_swar_layer_step_equals_the_oracle(abi, code50, method, eb_n0, n_iter, s
         assert np.abs(ref).max() == 31  # these batches reach the saturation limit: the merged clamp is exercised
 
 
+@pytest.mark.parametrize("factor,eb_n0,n_iter,spec", [(24, 3.4, 10, 1), (24, 4.2, 6, 0), (32, 3.6, 10, 1), (15, 3.4, 8, 1), (19, 3.0, 10, 0),
+                                                       (45, 3.6, 10, 1), (200, 3.6, 4, 1), (2000, 3.6, 4, 0)])
+def test_swar_layer_step_runs_normalised_min_sum_with_one_factor(abi, code50, factor, eb_n0, n_iter, spec):
+    """DecodeMethod 0 (CLDPC::Decode, CLDPC.cpp:287-375) on the byte-parallel layer step: the search keeps 16 levels of |t| and maps
+    them through cste(m) = min((m * Factor) >> 5, 7); Factor_1 == Factor_2 >= 15 (lnsfaid_swar.h sw_nms_fits)."""
+    lib = oa.load()
+    lib.lnsfaid_oracle_layered_en.restype = C.c_int
+    lib.lnsfaid_oracle_layered_en.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    em = C.CDLL(EMU)
+    em.swar_emul_layered.restype = C.c_int
+    em.swar_emul_layered.argtypes = [C.POINTER(abi.Code), C.POINTER(abi.Cfg), C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    cfg = abi.default_cfg(0, n_iter)
+    cfg.factor_1 = cfg.factor_2 = factor
+    fix = oa.ReferenceChannel(code50, 163, 13.0).groups(eb_n0, 1)
+    ref = np.empty(32 * code50.N, dtype=np.int8)
+    got = np.empty(32 * code50.N, dtype=np.int8)
+    assert lib.lnsfaid_oracle_layered_en(oa.Oracle(code50, cfg).h, fix.ctypes.data, n_iter, ref.ctypes.data) == 0
+    assert em.swar_emul_layered(C.byref(code50.code), C.byref(cfg), fix.ctypes.data, n_iter, spec, got.ctypes.data) == 0
+    bad = np.nonzero(ref != got)[0]
+    assert bad.size == 0, "En differs at %s: oracle %s, layer step %s" % (bad[:8].tolist(), ref[bad[:8]].tolist(), got[bad[:8]].tolist())
+
+
+def test_normalised_min_sum_factors_the_layer_step_takes(abi, code50):
+    """Two factors, or a factor whose cste() needs more than 16 levels of |t| (< 15) or wraps in 16 bits, stay on the other kernel:
+    the CPU run of the layer step refuses them like lnsfaid_create routes them."""
+    em = C.CDLL(EMU)
+    em.swar_emul_layered.restype = C.c_int
+    em.swar_emul_layered.argtypes = [C.POINTER(abi.Code), C.POINTER(abi.Cfg), C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    fix = oa.ReferenceChannel(code50, 163, 13.0).groups(3.6, 1)
+    got = np.empty(32 * code50.N, dtype=np.int8)
+    for f1, f2 in [(24, 28), (14, 14), (1, 1), (2185, 2185)]:  # 30 * 2185 wraps to 14 in 16 bits: cste(30) = 0
+        cfg = abi.default_cfg(0, 2)
+        cfg.factor_1, cfg.factor_2 = f1, f2
+        assert em.swar_emul_layered(C.byref(code50.code), C.byref(cfg), fix.ctypes.data, 2, 1, got.ctypes.data) == -1, (f1, f2)
+
+
 def _few_confident_errors(code50, rng, nflip, amp, noise):
     """All-zero codeword received almost cleanly, plus a few weight-3 variable nodes with the wrong sign at high confidence:
     few unsatisfied checks, and nodes whose three checks all fail - what EF_ELIMINATION 2 reacts to."""

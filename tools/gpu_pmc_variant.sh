@@ -1,8 +1,9 @@
 # usage: gpu_pmc_variant.sh "<extra -D flags>" "<bench args>" <tag>: rebuild kernel4 with flags, count VALU instructions per launch
 cd $GRAFT_REPO_ROOT
 REPO=$GRAFT_REPO_ROOT
-rm -f mod-interleaveavx_multithreads-faid_amd/csrc/lnsfaid_kernel4.o
-make -s -C mod-interleaveavx_multithreads-faid_amd/csrc HIPFLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -I. $1" > gpurun_out/pmcv_$3.build.log 2>&1 || { echo build failed; exit 1; }
+CSRC=mod-interleaveavx_multithreads-faid_amd/csrc
+trap 'make -s -C $REPO/$CSRC EXTRA= > $REPO/gpurun_out/pmcv_restore.build.log 2>&1' EXIT   # always end on the default build
+make -s -C $CSRC EXTRA="$1" > gpurun_out/pmcv_$3.build.log 2>&1 || { echo build failed; exit 1; }
 OUT=$REPO/gpurun_out/pmcv_$3
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

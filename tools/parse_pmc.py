@@ -47,6 +47,8 @@ out = {
     "tag": tag,
     "kernel_source_hash": open(os.path.join(src, "kernel_source_hash.txt")).read().strip(),
     "kernel": kernel_name[0],
+    "kernel_instance": kernel_name[0],   # bench.py replays the file only for this template instance ...
+    "library": open(os.path.join(src, "library_version.txt")).read().strip() if os.path.exists(os.path.join(src, "library_version.txt")) else None,  # ... of this build
     "codewords_per_launch": n_cw,
     "FETCH_SIZE_KiB_raw": dec_fetch_kib,
     "WRITE_SIZE_KiB_raw": dec_write_kib,
