@@ -148,10 +148,13 @@ def parse_args(argv=None):
     ap.add_argument("--method", type=int, default=2)
     ap.add_argument("--max-iter", type=int, default=10)
     ap.add_argument("--max-bf", type=int, default=None, help="override _maxBFiter (experiments only)")
+    ap.add_argument("--factor-1", type=int, default=None, help="Profile.txt Factor_1 (default: the shipped 1; NMS runs use e.g. 24)")
+    ap.add_argument("--factor-2", type=int, default=None, help="Profile.txt Factor_2 (default: the shipped 6)")
     ap.add_argument("--mod-type", type=int, default=2, choices=[2, 4], help="Profile.txt modType: 2 QPSK, 4 16-QAM")
     ap.add_argument("--scale", type=float, default=13.0, help="Profile.txt scale (12.5 for the hybrid 2B1C decoder)")
     ap.add_argument("--no-points", action="store_true", help="skip the 3.6 / 4.2 dB side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in call-shape leg (host/dropin_bench)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling leg")
     ap.add_argument("--cpu-groups", type=int, default=2048, help="groups of the cpu_baseline sample per Eb/N0 point")
     ap.add_argument("--cpu-seconds", type=float, default=1.0, help="minimum wall time of the cpu_baseline leg per Eb/N0 point")
@@ -265,6 +268,10 @@ def worker(args):
     cfg = pyabi.default_cfg(args.method, args.max_iter, lib)
     if args.max_bf is not None:
         cfg.max_bf_iter = args.max_bf
+    if args.factor_1 is not None:
+        cfg.factor_1 = args.factor_1
+    if args.factor_2 is not None:
+        cfg.factor_2 = args.factor_2
     if selftest:
         dec = SelftestDecoder(oa, code, cfg)
     else:
@@ -391,7 +398,8 @@ def worker(args):
     valu_inst, valu_src, valu_half_frac = None, None, None
     vpath = os.path.join(ROOT, "profiles", "valu_issue_per_launch.json")
     headline_workload = (args.method == 2 and abs(args.eb_n0 - 3.0) < 1e-6 and args.groups == 2048 and args.max_iter == 10
-                         and args.max_bf is None and args.mod_type == 2 and abs(args.scale - 13.0) < 1e-6 and not selftest
+                         and args.max_bf is None and args.factor_1 is None and args.factor_2 is None
+                         and args.mod_type == 2 and abs(args.scale - 13.0) < 1e-6 and not selftest
                          and "[" not in library)
 
     def replayable(rec):
@@ -586,6 +594,33 @@ def worker(args):
                     "the reference, but the FAID table is one pshufb where the reference emulates it with nine masked adds per "
                     "edge (CDecoder_FAID.cpp:710-851) and the dead flip_vote work is not done; the reference's own AVX-512 "
                     "build is not possible here (it needs Intel MKL's mkl.h)",
+        }
+
+    if rank == 0 and world == 1 and not args.no_dropin and not selftest and args.method in (1, 2, 5):
+        # The decoder in the reference's OWN call shape (not `value`): T host threads, one context each, ONE group of 32 frames
+        # per lnsfaid_decode call on pageable host buffers - what an unmodified CSimulate::Run does through the binding of
+        # INTEGRATION.md section 2 (reference CSimulate.cpp:136-164, main.cpp:164-172).  host/dropin_bench is run as a child
+        # process on the same GPU after the batched measurement; PCIe copies and every host-side cost are inside its clock.
+        exe = os.path.join(PKG_DIR, "host", "dropin_bench")
+        rows = []
+        if os.path.exists(exe):
+            for t in (1, 8, 64):
+                for reg in ([], ["--register"]):
+                    try:
+                        p = subprocess.run([exe, "--threads", str(t), "--calls", "40", "--eb-n0", str(args.eb_n0), "--method", str(args.method),
+                                            "--max-iter", str(args.max_iter), "--device", str(dev_index)] + reg,
+                                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+                        if p.returncode == 0 and p.stdout.strip().startswith("{"):
+                            rows.append(json.loads(p.stdout.strip().splitlines()[-1]))
+                    except Exception:
+                        pass
+        result["dropin"] = {
+            "what": "T host threads x one lnsfaid context each x ONE group of 32 frames per lnsfaid_decode call, host buffers in and out "
+                    "(pageable = plain malloc as the reference's CLDPC::Initial allocates them; registered = lnsfaid_host_register); "
+                    "aggregate_Gbps includes PCIe and every host-side cost; the headline `value` is the batched device-resident rate",
+            "unit": "Gb/s",
+            "runs": rows,
+            "best_aggregate_Gbps": max([r["aggregate_Gbps"] for r in rows], default=None),
         }
 
     dec.close()

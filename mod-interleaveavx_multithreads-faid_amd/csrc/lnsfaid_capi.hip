@@ -35,6 +35,11 @@ extern "C" hipError_t lf_launch_frontend(const uint32_t* d_seeds, const unsigned
                                          int n_check, int interleave, int8_t* d_fix, hipStream_t stream);
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+struct LfCombiner;
 static thread_local char g_hip_err[256] = "";
 /* Contexts alive in this process.  A host thread that waits for its stream by spinning (hipStreamSynchronize) is the
  * lowest-latency choice for a few contexts, and the worst one for the reference's call shape - one context per worker thread,
@@ -98,6 +103,8 @@ struct lnsfaid_ctx {
     lnsfaid_group_stats* d_io_stats = nullptr;
     int rows_per_lane = 0; /* 0: pick per configuration; 2 / 4: forced (lnsfaid_select_kernel) */
     int msg_store = 0;     /* 0: pick per code; 1: registers; 2: streamed through HBM (lnsfaid_select_message_store) */
+    struct LfCombiner* comb = nullptr; /* call combiner this one-group context is a member of (see below) */
+    int comb_slot = -1;
     const void* checked_fn = nullptr; /* kernel instance kernel_check() last looked at */
     int resident_wg = 0, lds_wg = 0;  /* its workgroups per CU: what the occupancy query says / what its LDS alone allows */
     void* comm = nullptr;      /* ncclComm_t for lnsfaid_allreduce_counters */
@@ -295,9 +302,12 @@ static int check_code_for_method(const LfDevCode* code, int method)
 
 /* ---- context ------------------------------------------------------------------------------------------- */
 extern "C" int lnsfaid_comm_destroy(lnsfaid_ctx* ctx);
+static int comb_join(lnsfaid_ctx* ctx);
+static void comb_leave(lnsfaid_ctx* ctx, int slot);
 extern "C" void lnsfaid_destroy(lnsfaid_ctx* ctx)
 {
     if (!ctx) return;
+    if (ctx->comb_slot >= 0) { comb_leave(ctx, ctx->comb_slot); ctx->comb_slot = -1; }
     g_live_contexts.fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -322,6 +332,7 @@ extern "C" void lnsfaid_destroy(lnsfaid_ctx* ctx)
     delete ctx;
 }
 
+static int alloc_state(lnsfaid_ctx* ctx);
 static int create_impl(lnsfaid_ctx* ctx, const lnsfaid_code* code, const lnsfaid_cfg* cfg)
 {
     int rc = build_code(code, &ctx->hcode);
@@ -332,6 +343,13 @@ static int create_impl(lnsfaid_ctx* ctx, const lnsfaid_code* code, const lnsfaid
     rc = check_code_for_method(&ctx->hcode, ctx->hcfg.method);
     if (rc) return rc;
     build_wcols(&ctx->hcode, ctx->hcfg.W);
+    return alloc_state(ctx);
+}
+
+/* device state of a context whose hcode / hcfg / device / max_groups are set */
+static int alloc_state(lnsfaid_ctx* ctx)
+{
+    ctx->n_var = ctx->hcode.n_var; ctx->n_check = ctx->hcode.n_check; ctx->k_info = ctx->hcode.k_info;
     ctx->lds_bytes = lf_lds_bytes(ctx->n_var, ctx->hcode.n_words, ctx->hcode.p_words);
     if (ctx->lds_bytes > 64 * 1024) return LNSFAID_E_CODE;
 
@@ -382,6 +400,7 @@ extern "C" int lnsfaid_create(lnsfaid_ctx** out, const lnsfaid_code* code, const
     g_live_contexts.fetch_add(1, std::memory_order_relaxed); /* (lnsfaid_destroy takes it back) */
     const int rc = create_impl(ctx, code, cfg);
     if (rc) { lnsfaid_destroy(ctx); return rc; }
+    ctx->comb_slot = comb_join(ctx); /* also sets ctx->comb */
     *out = ctx;
     return LNSFAID_OK;
 }
@@ -394,6 +413,9 @@ extern "C" int lnsfaid_set_cfg(lnsfaid_ctx* ctx, const lnsfaid_cfg* cfg)
     if (rc) return rc;
     rc = check_code_for_method(&ctx->hcode, n.method);
     if (rc) return rc;
+    /* the reference re-reads Profile.txt in every decode call (CDecoder_FAID.cpp:178-179), so a drop-in binding calls this once
+     * per call with what is almost always the same configuration: nothing to do then (no synchronisation, no upload) */
+    if (memcmp(&n, &ctx->hcfg, sizeof(n)) == 0) return LNSFAID_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (n.W != ctx->hcfg.W) { /* the bit-flipping column list depends on REGULAR_COL_WEIGHT */
@@ -403,6 +425,14 @@ extern "C" int lnsfaid_set_cfg(lnsfaid_ctx* ctx, const lnsfaid_cfg* cfg)
     ctx->hcfg = n;
     HIP_TRY(hipMemcpy(ctx->d_cfg, &ctx->hcfg, sizeof(LfDevCfg), hipMemcpyHostToDevice));
     return LNSFAID_OK;
+}
+
+/* the combiner's pool context takes the configuration of the batch it is about to decode (validated when the member built it) */
+static void apply_devcfg(lnsfaid_ctx* ctx, const LfDevCfg& n)
+{
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->hcfg = n; /* (same REGULAR_COL_WEIGHT as the pool's code: members are matched on the whole LfDevCode) */
+    (void)hipMemcpy(ctx->d_cfg, &ctx->hcfg, sizeof(LfDevCfg), hipMemcpyHostToDevice);
 }
 
 /* ---- the hot path ------------------------------------------------------------------------------------ */
@@ -521,8 +551,18 @@ extern "C" int lnsfaid_kernel_residency(lnsfaid_ctx* ctx, int32_t* workgroups_pe
     return LNSFAID_OK;
 }
 
+/* status_preloaded: ctx->d_status[0] already holds the decision point of every codeword (the call combiner marks the groups
+ * that take no part in a batch as finished); otherwise every codeword is fresh */
+static int decode_device_impl(lnsfaid_ctx* ctx, const int8_t* d_fixInput, size_t n_groups, int8_t* d_decodedBits,
+                              lnsfaid_group_stats* d_stats, bool status_preloaded);
 extern "C" int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput, size_t n_groups, int8_t* d_decodedBits,
                                      lnsfaid_group_stats* d_stats)
+{
+    return decode_device_impl(ctx, d_fixInput, n_groups, d_decodedBits, d_stats, false);
+}
+
+static int decode_device_impl(lnsfaid_ctx* ctx, const int8_t* d_fixInput, size_t n_groups, int8_t* d_decodedBits,
+                              lnsfaid_group_stats* d_stats, bool status_preloaded)
 {
     if (!ctx || (n_groups && (!d_fixInput || !d_decodedBits))) return LNSFAID_E_INVAL;
     if (n_groups > ctx->max_groups) return LNSFAID_E_INVAL;
@@ -562,7 +602,7 @@ extern "C" int lnsfaid_decode_device(lnsfaid_ctx* ctx, const int8_t* d_fixInput,
         if (chain < 1) chain = 1;
         if (chain > LF_MAX_CHAIN) chain = LF_MAX_CHAIN;
         for (int j = 0; j < chain; ++j) {
-            a.status_cur = (launch + j == 0) ? nullptr : ctx->d_status[cur];
+            a.status_cur = (launch + j == 0 && !status_preloaded) ? nullptr : ctx->d_status[cur];
             a.status_next = ctx->d_status[cur ^ 1];
             a.remaining = ctx->d_remaining + j;
             HIP_TRY(hipEventRecord(ctx->ev_chain[j], ctx->stream));
@@ -598,6 +638,245 @@ static int ensure_io(lnsfaid_ctx* ctx)
     HIP_TRY(hipMalloc(&ctx->d_io_stats, ctx->max_groups * sizeof(lnsfaid_group_stats)));
     return LNSFAID_OK;
 }
+
+/* ---- the call combiner: many contexts, one group per call -> few launches ------------------------------------------------
+ * The reference decodes ONE group of 32 frames per call from T worker threads, each owning a CLDPC (reference
+ * CSimulate.cpp:136-164, main.cpp:164-172), and the drop-in binding gives every CLDPC its own context.
+ * Taken literally that is T streams with a 32-wave launch each: the runtime multiplexes the streams onto a handful of hardware
+ * queues, so only a few of those launches are on the chip at a time, and every call pays its own copies, launches and waits
+ * (measured, profiles/r03_dropin: 64 threads reach 1.5 Gb/s of 70).  So contexts of ONE group on the same device that decode
+ * the same code share a combiner: a call copies its fixInput into a slot of a pinned staging area and sleeps; one worker thread
+ * per device gathers the calls that arrive within LF_COMB_WINDOW_US (or until every member has one pending), moves their slots
+ * to the device in one copy, decodes them in ONE launch sequence on a pool context of LF_COMB_SLOTS groups - groups without a
+ * pending call are marked finished, their workgroups exit at once -, copies the decisions back in one copy and wakes the
+ * callers, each of which copies its slot out.  Results are those of the direct path bit for bit (groups never interact).
+ * A context that is alone on its device, or whose kernel / message-store selection was changed by hand, takes the direct path;
+ * LNSFAID_COALESCE=0 switches the combiner off. */
+#define LF_COMB_SLOTS 128
+#define LF_COMB_WINDOW_US 60
+#define LF_COMB_DEVICES 16
+enum { LF_SLOT_FREE = 0, LF_SLOT_IDLE, LF_SLOT_PENDING, LF_SLOT_RUNNING, LF_SLOT_DONE };
+struct LfSlot {
+    int state = LF_SLOT_FREE;
+    int rc = 0;
+    LfDevCfg cfg;
+    lnsfaid_group_stats stats;
+};
+struct LfCombiner {
+    int device = 0;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::thread worker;
+    bool stop = false, dead = false;
+    lnsfaid_ctx* pool = nullptr; /* created by the worker for its first batch */
+    LfDevCode code;              /* what every member decodes (incl. the bit-flipping column list) */
+    size_t group_bytes = 0;
+    int8_t *h_in = nullptr, *h_out = nullptr; /* pinned, LF_COMB_SLOTS groups each; allocated when the second member joins */
+    int32_t* h_status = nullptr;              /* pinned, LF_COMB_SLOTS * 32 words */
+    lnsfaid_group_stats* h_stats = nullptr;   /* pinned */
+    LfSlot slots[LF_COMB_SLOTS];
+    int members = 0, pending = 0;
+    uint64_t batches = 0, calls = 0; /* statistics (LNSFAID_TRACE at shutdown) */
+};
+static std::mutex g_comb_mutex;
+static LfCombiner* g_comb[LF_COMB_DEVICES] = {};
+
+static bool comb_enabled()
+{
+    static const char* e = getenv("LNSFAID_COALESCE");
+    return !(e && e[0] == '0');
+}
+
+static void apply_devcfg(lnsfaid_ctx* ctx, const LfDevCfg& n); /* pool only: no validation, same code */
+
+static void comb_run_batch(LfCombiner* cb, const int* batch, int nb)
+{
+    lnsfaid_ctx* P = cb->pool;
+    int rc = LNSFAID_OK;
+    auto fail = [&](hipError_t e, const char* what) { if (rc == LNSFAID_OK && e != hipSuccess) rc = hip_fail(e, what); };
+    int lo = LF_COMB_SLOTS, hi = -1;
+    for (int i = 0; i < nb; ++i) { lo = batch[i] < lo ? batch[i] : lo; hi = batch[i] > hi ? batch[i] : hi; }
+    const size_t n = (size_t)hi + 1;
+    for (size_t g = 0; g < n; ++g) { /* groups without a call in this batch: finished before they start */
+        bool active = false;
+        for (int i = 0; i < nb; ++i) active = active || (size_t)batch[i] == g;
+        for (int l = 0; l < LNSFAID_GROUP; ++l) cb->h_status[g * LNSFAID_GROUP + l] = active ? 0 : LF_DONE;
+    }
+    fail(hipSetDevice(cb->device), "hipSetDevice");
+    if (rc == LNSFAID_OK && memcmp(&P->hcfg, &cb->slots[batch[0]].cfg, sizeof(LfDevCfg)) != 0) apply_devcfg(P, cb->slots[batch[0]].cfg);
+    const size_t gb = cb->group_bytes, span = (size_t)(hi - lo + 1);
+    fail(hipMemcpyAsync(P->d_status[0], cb->h_status, n * LNSFAID_GROUP * sizeof(int32_t), hipMemcpyHostToDevice, P->stream), "status upload");
+    fail(hipMemcpyAsync(P->d_io_in + (size_t)lo * gb, cb->h_in + (size_t)lo * gb, span * gb, hipMemcpyHostToDevice, P->stream), "fixInput upload");
+    if (rc == LNSFAID_OK) rc = decode_device_impl(P, P->d_io_in, n, P->d_io_out, P->d_io_stats, true);
+    if (rc == LNSFAID_OK) {
+        fail(hipMemcpyAsync(cb->h_out + (size_t)lo * gb, P->d_io_out + (size_t)lo * gb, span * gb, hipMemcpyDeviceToHost, P->stream), "decodedBits download");
+        fail(hipMemcpyAsync(cb->h_stats + lo, P->d_io_stats + lo, span * sizeof(lnsfaid_group_stats), hipMemcpyDeviceToHost, P->stream), "stats download");
+        if (rc == LNSFAID_OK) rc = stream_wait(P);
+    }
+    std::lock_guard<std::mutex> lk(cb->m);
+    for (int i = 0; i < nb; ++i) {
+        LfSlot& s = cb->slots[batch[i]];
+        s.rc = rc;
+        s.stats = cb->h_stats[batch[i]];
+        s.state = LF_SLOT_DONE;
+    }
+    cb->batches += 1; cb->calls += (uint64_t)nb;
+    cb->cv_done.notify_all();
+}
+
+static void comb_worker(LfCombiner* cb)
+{
+    std::unique_lock<std::mutex> lk(cb->m);
+    for (;;) {
+        cb->cv_work.wait(lk, [&] { return cb->pending > 0 || cb->stop; });
+        if (cb->stop) break;
+        /* gather: until every member has a call pending or the window has passed since the first one was seen */
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(LF_COMB_WINDOW_US);
+        while (cb->pending < cb->members && !cb->stop) {
+            if (cb->cv_work.wait_until(lk, deadline) == std::cv_status::timeout) break;
+        }
+        if (cb->stop) break;
+        int batch[LF_COMB_SLOTS], nb = 0;
+        const LfDevCfg* cfg = nullptr; /* one configuration per batch: the first pending one's */
+        for (int i = 0; i < LF_COMB_SLOTS; ++i) {
+            LfSlot& s = cb->slots[i];
+            if (s.state != LF_SLOT_PENDING) continue;
+            if (!cfg) cfg = &s.cfg;
+            if (memcmp(cfg, &s.cfg, sizeof(LfDevCfg)) != 0) continue; /* next batch */
+            s.state = LF_SLOT_RUNNING;
+            batch[nb++] = i;
+        }
+        cb->pending -= nb;
+        if (nb == 0) continue;
+        if (!cb->pool) { /* first batch: the pool context (device state for LF_COMB_SLOTS groups) */
+            lk.unlock();
+            int rc = LNSFAID_OK;
+            lnsfaid_ctx* P = new (std::nothrow) lnsfaid_ctx();
+            if (!P) rc = LNSFAID_E_NOMEM;
+            if (!rc) {
+                P->device = cb->device; P->max_groups = LF_COMB_SLOTS;
+                P->hcode = cb->code; P->hcfg = cb->slots[batch[0]].cfg;
+                g_live_contexts.fetch_add(1, std::memory_order_relaxed);
+                rc = alloc_state(P);
+                if (!rc) rc = ensure_io(P);
+                if (rc) { lnsfaid_destroy(P); P = nullptr; }
+            }
+            lk.lock();
+            if (rc) { /* the members fall back to their own contexts from now on */
+                cb->dead = true;
+                for (int i = 0; i < nb; ++i) { cb->slots[batch[i]].rc = rc; cb->slots[batch[i]].state = LF_SLOT_DONE; }
+                cb->cv_done.notify_all();
+                continue;
+            }
+            cb->pool = P;
+        }
+        lk.unlock();
+        comb_run_batch(cb, batch, nb);
+        lk.lock();
+    }
+}
+
+/* a one-group context joins the combiner of its device (created on demand); -1: it stays on its own */
+static int comb_join(lnsfaid_ctx* ctx)
+{
+    if (!comb_enabled() || ctx->max_groups != 1 || ctx->device < 0 || ctx->device >= LF_COMB_DEVICES) return -1;
+    std::lock_guard<std::mutex> g(g_comb_mutex);
+    LfCombiner* cb = g_comb[ctx->device];
+    if (!cb) { /* the first one-group context of the device: a record only - staging area and worker come with the second */
+        cb = new (std::nothrow) LfCombiner();
+        if (!cb) return -1;
+        cb->device = ctx->device;
+        cb->code = ctx->hcode;
+        cb->group_bytes = (size_t)LNSFAID_GROUP * (size_t)ctx->n_var;
+        g_comb[ctx->device] = cb;
+    }
+    std::lock_guard<std::mutex> lk(cb->m);
+    if (cb->dead || memcmp(&cb->code, &ctx->hcode, sizeof(LfDevCode)) != 0) return -1; /* another code: on its own */
+    if (cb->members >= 1 && !cb->h_in) { /* there is something to combine from now on */
+        const size_t bytes = (size_t)LF_COMB_SLOTS * cb->group_bytes;
+        if (hipSetDevice(cb->device) != hipSuccess
+            || hipHostMalloc((void**)&cb->h_in, bytes, hipHostMallocDefault) != hipSuccess
+            || hipHostMalloc((void**)&cb->h_out, bytes, hipHostMallocDefault) != hipSuccess
+            || hipHostMalloc((void**)&cb->h_status, (size_t)LF_COMB_SLOTS * LNSFAID_GROUP * sizeof(int32_t), hipHostMallocDefault) != hipSuccess
+            || hipHostMalloc((void**)&cb->h_stats, (size_t)LF_COMB_SLOTS * sizeof(lnsfaid_group_stats), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            if (cb->h_in) (void)hipHostFree(cb->h_in);
+            if (cb->h_out) (void)hipHostFree(cb->h_out);
+            if (cb->h_status) (void)hipHostFree(cb->h_status);
+            if (cb->h_stats) (void)hipHostFree(cb->h_stats);
+            cb->h_in = cb->h_out = nullptr; cb->h_status = nullptr; cb->h_stats = nullptr;
+            cb->dead = true; /* everybody stays on the direct path */
+            return -1;
+        }
+        cb->worker = std::thread(comb_worker, cb);
+    }
+    for (int i = 0; i < LF_COMB_SLOTS; ++i)
+        if (cb->slots[i].state == LF_SLOT_FREE) { cb->slots[i].state = LF_SLOT_IDLE; cb->members += 1; ctx->comb = cb; return i; }
+    return -1; /* more contexts than slots */
+}
+
+static void comb_leave(lnsfaid_ctx* ctx, int slot)
+{
+    LfCombiner* cb = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_comb_mutex);
+        cb = ctx->comb;
+        if (!cb) return;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(cb->m);
+            cb->slots[slot].state = LF_SLOT_FREE;
+            cb->members -= 1;
+            last = cb->members == 0;
+            if (last) cb->stop = true;
+            cb->cv_work.notify_all();
+        }
+        if (!last) return;
+        if (g_comb[cb->device] == cb) g_comb[cb->device] = nullptr; /* a later context starts a new one */
+    }
+    if (cb->worker.joinable()) cb->worker.join();
+    static const bool trace = getenv("LNSFAID_TRACE") != nullptr;
+    if (trace && cb->batches) fprintf(stderr, "[lnsfaid] call combiner of device %d: %llu calls in %llu batches (%.1f per launch sequence)\n", cb->device,
+                                      (unsigned long long)cb->calls, (unsigned long long)cb->batches, (double)cb->calls / (double)cb->batches);
+    if (cb->pool) lnsfaid_destroy(cb->pool);
+    if (cb->h_in) { (void)hipHostFree(cb->h_in); (void)hipHostFree(cb->h_out); (void)hipHostFree(cb->h_status); (void)hipHostFree(cb->h_stats); }
+    delete cb;
+}
+
+/* 1: decoded through the combiner (*rc_out = result); 0: not applicable now, take the direct path */
+static int comb_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, int8_t* decodedBits, lnsfaid_group_stats* stats, int* rc_out)
+{
+    if (ctx->comb_slot < 0 || ctx->rows_per_lane != 0 || ctx->msg_store != 0) return 0;
+    LfCombiner* cb = ctx->comb;
+    const int slot = ctx->comb_slot;
+    {
+        std::lock_guard<std::mutex> lk(cb->m);
+        if (cb->dead || cb->members < 2 || !cb->h_in) return 0; /* alone on the device: nothing to combine with */
+        if (memcmp(&cb->code, &ctx->hcode, sizeof(LfDevCode)) != 0) return 0; /* lnsfaid_set_cfg changed REGULAR_COL_WEIGHT */
+    }
+    memcpy(cb->h_in + (size_t)slot * cb->group_bytes, fixInput, cb->group_bytes); /* every caller copies its own slot, in parallel */
+    int rc;
+    {
+        std::unique_lock<std::mutex> lk(cb->m);
+        LfSlot& s = cb->slots[slot];
+        s.cfg = ctx->hcfg;
+        s.state = LF_SLOT_PENDING;
+        cb->pending += 1;
+        cb->cv_work.notify_one();
+        if (!cb->cv_done.wait_for(lk, std::chrono::seconds(120), [&] { return s.state == LF_SLOT_DONE; })) {
+            snprintf(g_hip_err, sizeof(g_hip_err), "call combiner: no result after 120 s");
+            *rc_out = LNSFAID_E_INTERNAL;
+            return 1;
+        }
+        rc = s.rc;
+        if (stats) *stats = s.stats;
+        s.state = LF_SLOT_IDLE;
+    }
+    if (rc == LNSFAID_OK) memcpy(decodedBits, cb->h_out + (size_t)slot * cb->group_bytes, cb->group_bytes);
+    *rc_out = rc;
+    return 1;
+}
+
 
 extern "C" int lnsfaid_frontend_set_interleave(lnsfaid_ctx* ctx, int32_t interleave_mod_type)
 {
@@ -667,6 +946,10 @@ extern "C" int lnsfaid_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, size_t n
     if (!ctx || (n_groups && (!fixInput || !decodedBits))) return LNSFAID_E_INVAL;
     if (n_groups > ctx->max_groups) return LNSFAID_E_INVAL;
     if (n_groups == 0) return LNSFAID_OK;
+    {   /* a one-group context among others on its device: through the call combiner */
+        int rcc = 0;
+        if (comb_decode(ctx, fixInput, decodedBits, stats, &rcc)) return rcc;
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_io(ctx);
     if (rc) return rc;

@@ -165,3 +165,47 @@ def test_config5_hybrid_2b1c_16qam_at_batch_size(abi, code50):
         assert bad.size == 0, "frames differ from the CPU port at %.1f dB: %s" % (eb, bad[:16].tolist())
         assert np.array_equal(st, ref_st)
         assert 0 < st[:, 0].mean() < 10  # inside the waterfall: early stop active, not everything converges at once
+
+
+def test_contexts_decoding_concurrently_through_the_call_combiner(abi, code50):
+    """The reference's call shape (one CLDPC per worker thread, one group of 32 frames per call: CSimulate.cpp:136-164,
+    main.cpp:164-172) through the binding of INTEGRATION.md 2: several one-group contexts on one GPU, every one called from its
+    own host thread at the same time.  The library combines such calls into common launches (lnsfaid_capi.hip, call combiner);
+    every call must still return exactly its own group's oracle result - also when the threads use different DecodeMethods
+    (batches are formed per configuration) and when a context is created or destroyed while the others are decoding."""
+    import threading
+    n_threads, n_calls = 6, 5
+    methods = [2, 2, 2, 5, 1, 2]
+    fixes, refs = [], []
+    for t in range(n_threads):
+        cfg = abi.default_cfg(methods[t], 10)
+        fix = oa.ReferenceChannel(code50, 300 + t, 13.0).groups(3.5 if t % 2 else 4.0, n_calls)
+        ref, ref_stats = oa.Oracle(code50, cfg).decode(fix, n_calls)
+        fixes.append(fix.reshape(n_calls, -1))
+        refs.append((ref.reshape(n_calls, -1), ref_stats))
+    errors = []
+    start = threading.Barrier(n_threads)
+
+    def worker(t):
+        try:
+            dec = abi.Decoder(code50, abi.default_cfg(methods[t], 10), device=0, max_groups=1)
+            start.wait()
+            for rep in range(2):
+                for c in range(n_calls):
+                    out, st = dec.decode(np.ascontiguousarray(fixes[t][c]), 1)
+                    if not np.array_equal(out, refs[t][0][c]) or st.tolist() != [refs[t][1][c].tolist()]:
+                        errors.append((t, rep, c, st.tolist(), refs[t][1][c].tolist()))
+                if t == 0 and rep == 0:  # a member leaves and a new one joins while the others keep decoding
+                    dec.close()
+                    dec = abi.Decoder(code50, abi.default_cfg(methods[t], 10), device=0, max_groups=1)
+            dec.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=600)
+    assert not any(th.is_alive() for th in threads), "a decode call did not return"
+    assert not errors, errors[:4]
