@@ -653,8 +653,12 @@ static int ensure_io(lnsfaid_ctx* ctx)
  * A context that is alone on its device, or whose kernel / message-store selection was changed by hand, takes the direct path;
  * LNSFAID_COALESCE=0 switches the combiner off. */
 #define LF_COMB_SLOTS 128
-#define LF_COMB_WINDOW_US 60
+#define LF_COMB_QUIET_US 150  /* a batch is closed when no further call has arrived for this long ...                      */
+#define LF_COMB_WINDOW_US 1500 /* ... or this long after its first call, or as soon as every member has a call pending       */
 #define LF_COMB_DEVICES 16
+#define LF_COMB_WORKERS 4     /* upper limit of the batches in flight (LNSFAID_COMB_WORKERS, default 2): the transfers of one overlap
+                               * the decode of the others */
+#define LF_COMB_MIN_MEMBERS 4 /* fewer one-group contexts than this on a device: each keeps to its own stream (measured faster) */
 enum { LF_SLOT_FREE = 0, LF_SLOT_IDLE, LF_SLOT_PENDING, LF_SLOT_RUNNING, LF_SLOT_DONE };
 struct LfSlot {
     int state = LF_SLOT_FREE;
@@ -666,20 +670,34 @@ struct LfCombiner {
     int device = 0;
     std::mutex m;
     std::condition_variable cv_work, cv_done;
-    std::thread worker;
+    std::thread worker[LF_COMB_WORKERS];
     bool stop = false, dead = false;
-    lnsfaid_ctx* pool = nullptr; /* created by the worker for its first batch */
+    bool gathering = false;                        /* one worker at a time collects a batch */
+    int running = 0;                               /* calls claimed by a worker and not yet answered */
+    lnsfaid_ctx* pool[LF_COMB_WORKERS] = {};       /* one per worker, created for its first batch */
     LfDevCode code;              /* what every member decodes (incl. the bit-flipping column list) */
     size_t group_bytes = 0;
     int8_t *h_in = nullptr, *h_out = nullptr; /* pinned, LF_COMB_SLOTS groups each; allocated when the second member joins */
-    int32_t* h_status = nullptr;              /* pinned, LF_COMB_SLOTS * 32 words */
-    lnsfaid_group_stats* h_stats = nullptr;   /* pinned */
+    int8_t *d_in_map = nullptr, *d_out_map = nullptr; /* the same memory as the device sees it (zero copy), null if not mapped */
+    int32_t* h_status = nullptr;              /* pinned, LF_COMB_WORKERS x LF_COMB_SLOTS * 32 words */
+    lnsfaid_group_stats* h_stats = nullptr;   /* pinned, LF_COMB_WORKERS x LF_COMB_SLOTS */
     LfSlot slots[LF_COMB_SLOTS];
     int members = 0, pending = 0;
     uint64_t batches = 0, calls = 0; /* statistics (LNSFAID_TRACE at shutdown) */
+    double gather_ms = 0, device_ms = 0;
 };
 static std::mutex g_comb_mutex;
 static LfCombiner* g_comb[LF_COMB_DEVICES] = {};
+
+static int comb_workers()
+{
+    static const int n = [] {
+        const char* e = getenv("LNSFAID_COMB_WORKERS");
+        const int v = e ? atoi(e) : 2;
+        return v < 1 ? 1 : (v > LF_COMB_WORKERS ? LF_COMB_WORKERS : v);
+    }();
+    return n;
+}
 
 static bool comb_enabled()
 {
@@ -689,9 +707,11 @@ static bool comb_enabled()
 
 static void apply_devcfg(lnsfaid_ctx* ctx, const LfDevCfg& n); /* pool only: no validation, same code */
 
-static void comb_run_batch(LfCombiner* cb, const int* batch, int nb)
+static void comb_run_batch(LfCombiner* cb, int w, const int* batch, int nb)
 {
-    lnsfaid_ctx* P = cb->pool;
+    lnsfaid_ctx* P = cb->pool[w];
+    int32_t* h_status = cb->h_status + (size_t)w * LF_COMB_SLOTS * LNSFAID_GROUP;
+    lnsfaid_group_stats* h_stats = cb->h_stats + (size_t)w * LF_COMB_SLOTS;
     int rc = LNSFAID_OK;
     auto fail = [&](hipError_t e, const char* what) { if (rc == LNSFAID_OK && e != hipSuccess) rc = hip_fail(e, what); };
     int lo = LF_COMB_SLOTS, hi = -1;
@@ -700,45 +720,70 @@ static void comb_run_batch(LfCombiner* cb, const int* batch, int nb)
     for (size_t g = 0; g < n; ++g) { /* groups without a call in this batch: finished before they start */
         bool active = false;
         for (int i = 0; i < nb; ++i) active = active || (size_t)batch[i] == g;
-        for (int l = 0; l < LNSFAID_GROUP; ++l) cb->h_status[g * LNSFAID_GROUP + l] = active ? 0 : LF_DONE;
+        for (int l = 0; l < LNSFAID_GROUP; ++l) h_status[g * LNSFAID_GROUP + l] = active ? 0 : LF_DONE;
     }
     fail(hipSetDevice(cb->device), "hipSetDevice");
     if (rc == LNSFAID_OK && memcmp(&P->hcfg, &cb->slots[batch[0]].cfg, sizeof(LfDevCfg)) != 0) apply_devcfg(P, cb->slots[batch[0]].cfg);
     const size_t gb = cb->group_bytes, span = (size_t)(hi - lo + 1);
-    fail(hipMemcpyAsync(P->d_status[0], cb->h_status, n * LNSFAID_GROUP * sizeof(int32_t), hipMemcpyHostToDevice, P->stream), "status upload");
-    fail(hipMemcpyAsync(P->d_io_in + (size_t)lo * gb, cb->h_in + (size_t)lo * gb, span * gb, hipMemcpyHostToDevice, P->stream), "fixInput upload");
-    if (rc == LNSFAID_OK) rc = decode_device_impl(P, P->d_io_in, n, P->d_io_out, P->d_io_stats, true);
+    fail(hipMemcpyAsync(P->d_status[0], h_status, n * LNSFAID_GROUP * sizeof(int32_t), hipMemcpyHostToDevice, P->stream), "status upload");
+    /* The staging area is pinned, device-mapped host memory.  zero copy: the kernel reads every LLR once (input staging) and
+     * writes every decision once, so it can do both straight over PCIe - no separate copy phases in front of and behind the
+     * launch, and the transfers of one batch run under the compute of the other.  LNSFAID_COMB_COPY=1: explicit copies. */
+    static const bool copy_mode = getenv("LNSFAID_COMB_COPY") != nullptr;
+    const int8_t* k_in = cb->d_in_map;
+    int8_t* k_out = cb->d_out_map;
+    if (copy_mode || !k_in || !k_out) {
+        fail(hipMemcpyAsync(P->d_io_in + (size_t)lo * gb, cb->h_in + (size_t)lo * gb, span * gb, hipMemcpyHostToDevice, P->stream), "fixInput upload");
+        k_in = P->d_io_in; k_out = P->d_io_out;
+    }
+    if (rc == LNSFAID_OK) rc = decode_device_impl(P, k_in, n, k_out, P->d_io_stats, true);
     if (rc == LNSFAID_OK) {
-        fail(hipMemcpyAsync(cb->h_out + (size_t)lo * gb, P->d_io_out + (size_t)lo * gb, span * gb, hipMemcpyDeviceToHost, P->stream), "decodedBits download");
-        fail(hipMemcpyAsync(cb->h_stats + lo, P->d_io_stats + lo, span * sizeof(lnsfaid_group_stats), hipMemcpyDeviceToHost, P->stream), "stats download");
+        if (k_out == P->d_io_out)
+            fail(hipMemcpyAsync(cb->h_out + (size_t)lo * gb, P->d_io_out + (size_t)lo * gb, span * gb, hipMemcpyDeviceToHost, P->stream), "decodedBits download");
+        fail(hipMemcpyAsync(h_stats + lo, P->d_io_stats + lo, span * sizeof(lnsfaid_group_stats), hipMemcpyDeviceToHost, P->stream), "stats download");
         if (rc == LNSFAID_OK) rc = stream_wait(P);
     }
     std::lock_guard<std::mutex> lk(cb->m);
     for (int i = 0; i < nb; ++i) {
         LfSlot& s = cb->slots[batch[i]];
         s.rc = rc;
-        s.stats = cb->h_stats[batch[i]];
+        s.stats = h_stats[batch[i]];
         s.state = LF_SLOT_DONE;
     }
+    cb->running -= nb;
     cb->batches += 1; cb->calls += (uint64_t)nb;
     cb->cv_done.notify_all();
+    cb->cv_work.notify_all(); /* a gathering worker counts the calls in flight */
 }
 
-static void comb_worker(LfCombiner* cb)
+static void comb_worker(LfCombiner* cb, int w)
 {
     std::unique_lock<std::mutex> lk(cb->m);
     for (;;) {
-        cb->cv_work.wait(lk, [&] { return cb->pending > 0 || cb->stop; });
+        cb->cv_work.wait(lk, [&] { return cb->stop || (cb->pending > 0 && !cb->gathering); });
         if (cb->stop) break;
-        /* gather: until every member has a call pending or the window has passed since the first one was seen */
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(LF_COMB_WINDOW_US);
-        while (cb->pending < cb->members && !cb->stop) {
-            if (cb->cv_work.wait_until(lk, deadline) == std::cv_status::timeout) break;
+        /* gather.  The decode time of a batch hardly depends on its size (a launch of 64 groups just fills the chip) and
+         * LF_COMB_WORKERS batches are in flight at a time, so a batch should be a 1 / LF_COMB_WORKERS share of the members: wait
+         * until that many calls are pending, or every member is accounted for (pending, or in flight with another worker), or no
+         * further call has arrived for LF_COMB_QUIET_US, or LF_COMB_WINDOW_US have passed since the first one was seen */
+        cb->gathering = true;
+        const auto t_first = std::chrono::steady_clock::now();
+        const auto deadline = t_first + std::chrono::microseconds(LF_COMB_WINDOW_US);
+        for (;;) {
+            const int share = (cb->members + comb_workers() - 1) / comb_workers();
+            if (cb->stop || cb->pending >= share || cb->pending + cb->running >= cb->members) break;
+            const int seen = cb->pending, seen_running = cb->running;
+            auto quiet = std::chrono::steady_clock::now() + std::chrono::microseconds(LF_COMB_QUIET_US);
+            if (quiet > deadline) quiet = deadline;
+            cb->cv_work.wait_until(lk, quiet, [&] { return cb->pending != seen || cb->running != seen_running || cb->stop; });
+            if (cb->pending == seen && cb->running == seen_running) break; /* quiet (or the window is over) */
         }
-        if (cb->stop) break;
+        if (cb->stop) { cb->gathering = false; break; }
+        cb->gather_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_first).count();
         int batch[LF_COMB_SLOTS], nb = 0;
+        const int cap = cb->members > 8 * comb_workers() ? (cb->members + comb_workers() - 1) / comb_workers() : LF_COMB_SLOTS;
         const LfDevCfg* cfg = nullptr; /* one configuration per batch: the first pending one's */
-        for (int i = 0; i < LF_COMB_SLOTS; ++i) {
+        for (int i = 0; i < LF_COMB_SLOTS && nb < cap; ++i) {
             LfSlot& s = cb->slots[i];
             if (s.state != LF_SLOT_PENDING) continue;
             if (!cfg) cfg = &s.cfg;
@@ -747,8 +792,11 @@ static void comb_worker(LfCombiner* cb)
             batch[nb++] = i;
         }
         cb->pending -= nb;
+        cb->running += nb;
+        cb->gathering = false;
+        cb->cv_work.notify_all(); /* the next batch may be gathered by another worker while this one is on the device */
         if (nb == 0) continue;
-        if (!cb->pool) { /* first batch: the pool context (device state for LF_COMB_SLOTS groups) */
+        if (!cb->pool[w]) { /* this worker's first batch: its pool context (device state for LF_COMB_SLOTS groups) */
             lk.unlock();
             int rc = LNSFAID_OK;
             lnsfaid_ctx* P = new (std::nothrow) lnsfaid_ctx();
@@ -765,14 +813,17 @@ static void comb_worker(LfCombiner* cb)
             if (rc) { /* the members fall back to their own contexts from now on */
                 cb->dead = true;
                 for (int i = 0; i < nb; ++i) { cb->slots[batch[i]].rc = rc; cb->slots[batch[i]].state = LF_SLOT_DONE; }
+                cb->running -= nb;
                 cb->cv_done.notify_all();
                 continue;
             }
-            cb->pool = P;
+            cb->pool[w] = P;
         }
         lk.unlock();
-        comb_run_batch(cb, batch, nb);
+        const auto t_dev = std::chrono::steady_clock::now();
+        comb_run_batch(cb, w, batch, nb);
         lk.lock();
+        cb->device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev).count();
     }
 }
 
@@ -795,10 +846,10 @@ static int comb_join(lnsfaid_ctx* ctx)
     if (cb->members >= 1 && !cb->h_in) { /* there is something to combine from now on */
         const size_t bytes = (size_t)LF_COMB_SLOTS * cb->group_bytes;
         if (hipSetDevice(cb->device) != hipSuccess
-            || hipHostMalloc((void**)&cb->h_in, bytes, hipHostMallocDefault) != hipSuccess
-            || hipHostMalloc((void**)&cb->h_out, bytes, hipHostMallocDefault) != hipSuccess
-            || hipHostMalloc((void**)&cb->h_status, (size_t)LF_COMB_SLOTS * LNSFAID_GROUP * sizeof(int32_t), hipHostMallocDefault) != hipSuccess
-            || hipHostMalloc((void**)&cb->h_stats, (size_t)LF_COMB_SLOTS * sizeof(lnsfaid_group_stats), hipHostMallocDefault) != hipSuccess) {
+            || hipHostMalloc((void**)&cb->h_in, bytes, hipHostMallocMapped) != hipSuccess
+            || hipHostMalloc((void**)&cb->h_out, bytes, hipHostMallocMapped) != hipSuccess
+            || hipHostMalloc((void**)&cb->h_status, (size_t)LF_COMB_WORKERS * LF_COMB_SLOTS * LNSFAID_GROUP * sizeof(int32_t), hipHostMallocDefault) != hipSuccess
+            || hipHostMalloc((void**)&cb->h_stats, (size_t)LF_COMB_WORKERS * LF_COMB_SLOTS * sizeof(lnsfaid_group_stats), hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             if (cb->h_in) (void)hipHostFree(cb->h_in);
             if (cb->h_out) (void)hipHostFree(cb->h_out);
@@ -808,7 +859,12 @@ static int comb_join(lnsfaid_ctx* ctx)
             cb->dead = true; /* everybody stays on the direct path */
             return -1;
         }
-        cb->worker = std::thread(comb_worker, cb);
+        if (hipHostGetDevicePointer((void**)&cb->d_in_map, cb->h_in, 0) != hipSuccess
+            || hipHostGetDevicePointer((void**)&cb->d_out_map, cb->h_out, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            cb->d_in_map = cb->d_out_map = nullptr; /* explicit copies then */
+        }
+        for (int w = 0; w < comb_workers(); ++w) cb->worker[w] = std::thread(comb_worker, cb, w);
     }
     for (int i = 0; i < LF_COMB_SLOTS; ++i)
         if (cb->slots[i].state == LF_SLOT_FREE) { cb->slots[i].state = LF_SLOT_IDLE; cb->members += 1; ctx->comb = cb; return i; }
@@ -834,11 +890,13 @@ static void comb_leave(lnsfaid_ctx* ctx, int slot)
         if (!last) return;
         if (g_comb[cb->device] == cb) g_comb[cb->device] = nullptr; /* a later context starts a new one */
     }
-    if (cb->worker.joinable()) cb->worker.join();
+    for (auto& th : cb->worker) if (th.joinable()) th.join();
     static const bool trace = getenv("LNSFAID_TRACE") != nullptr;
-    if (trace && cb->batches) fprintf(stderr, "[lnsfaid] call combiner of device %d: %llu calls in %llu batches (%.1f per launch sequence)\n", cb->device,
-                                      (unsigned long long)cb->calls, (unsigned long long)cb->batches, (double)cb->calls / (double)cb->batches);
-    if (cb->pool) lnsfaid_destroy(cb->pool);
+    if (trace && cb->batches)
+        fprintf(stderr, "[lnsfaid] call combiner of device %d: %llu calls in %llu batches (%.1f per batch); per batch %.3f ms gathering, %.3f ms copies + decode\n",
+                cb->device, (unsigned long long)cb->calls, (unsigned long long)cb->batches, (double)cb->calls / (double)cb->batches,
+                cb->gather_ms / (double)cb->batches, cb->device_ms / (double)cb->batches);
+    for (auto P : cb->pool) if (P) lnsfaid_destroy(P);
     if (cb->h_in) { (void)hipHostFree(cb->h_in); (void)hipHostFree(cb->h_out); (void)hipHostFree(cb->h_status); (void)hipHostFree(cb->h_stats); }
     delete cb;
 }
@@ -851,7 +909,7 @@ static int comb_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, int8_t* decoded
     const int slot = ctx->comb_slot;
     {
         std::lock_guard<std::mutex> lk(cb->m);
-        if (cb->dead || cb->members < 2 || !cb->h_in) return 0; /* alone on the device: nothing to combine with */
+        if (cb->dead || cb->members < LF_COMB_MIN_MEMBERS || !cb->h_in) return 0; /* too few to gain from combining: direct path */
         if (memcmp(&cb->code, &ctx->hcode, sizeof(LfDevCode)) != 0) return 0; /* lnsfaid_set_cfg changed REGULAR_COL_WEIGHT */
     }
     memcpy(cb->h_in + (size_t)slot * cb->group_bytes, fixInput, cb->group_bytes); /* every caller copies its own slot, in parallel */
@@ -862,7 +920,7 @@ static int comb_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, int8_t* decoded
         s.cfg = ctx->hcfg;
         s.state = LF_SLOT_PENDING;
         cb->pending += 1;
-        cb->cv_work.notify_one();
+        cb->cv_work.notify_all(); /* (at most LF_COMB_WORKERS waiters) */
         if (!cb->cv_done.wait_for(lk, std::chrono::seconds(120), [&] { return s.state == LF_SLOT_DONE; })) {
             snprintf(g_hip_err, sizeof(g_hip_err), "call combiner: no result after 120 s");
             *rc_out = LNSFAID_E_INTERNAL;

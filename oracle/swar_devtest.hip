@@ -73,6 +73,9 @@ __global__ __launch_bounds__(64) void k_layers(int n_var, int nbr, const int* de
     for (int i = lane; i < n_var / 4; i += 64) o32[i] = s32[i];
 }
 
+/* layout check for the ctypes mirror in tests/test_gpu_swar.py */
+extern "C" int swar_devtest_sizeof_params(void) { return (int)sizeof(SwParams); }
+
 extern "C" int swar_devtest_layers(int n_cw, int n_var, int nbr, const int* deg, const uint32_t* sb, const SwParams* p6, int n_iter,
                                    uint8_t* img)
 {

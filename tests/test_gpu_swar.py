@@ -18,7 +18,15 @@ EMU = os.path.join(oa.ORACLE_DIR, "libswar_emul.so")
 class SwParams(C.Structure):
     _fields_ = [("lut_lo", C.c_uint32), ("lut_hi", C.c_uint32), ("ef_lo", C.c_uint32), ("ef_hi", C.c_uint32),
                 ("f1", C.c_int32), ("f2", C.c_int32), ("window", C.c_int32), ("ef_tables", C.c_int32),
+                ("nms_t", C.c_uint32 * 4),
                 ("oms_lo", C.c_uint32 * 2), ("oms_hi", C.c_uint32 * 2)]  # = struct SwParams (the tables: min-sum decoders only)
+
+
+def _check_layout(dev):
+    """this mirror of struct SwParams against the header the device library was built from (a field added there and forgotten
+    here once made the layer test fail with wrong En everywhere: profiles/r02a/gpu_tests.log)"""
+    dev.swar_devtest_sizeof_params.restype = C.c_int
+    assert dev.swar_devtest_sizeof_params() == C.sizeof(SwParams), "tests/test_gpu_swar.py: SwParams differs from lnsfaid_swar.h"
 
 
 def test_instruction_semantics_match_the_host_restatements():
@@ -43,6 +51,7 @@ def test_instruction_semantics_match_the_host_restatements():
 @pytest.mark.parametrize("n_iter", [1, 2, 10])
 def test_layer_step_on_the_device_equals_the_cpu_run(abi, code50, n_iter):
     dev, emu = C.CDLL(DEV), C.CDLL(EMU)
+    _check_layout(dev)
     cfg = abi.default_cfg(2, 10)
     N, M = code50.N, code50.M
     K = N - M
@@ -75,7 +84,7 @@ def test_layer_step_on_the_device_equals_the_cpu_run(abi, code50, n_iter):
                 lo |= val << (8 * a)
             else:
                 hi |= val << (8 * (a - 4))
-        p6[it] = SwParams(lo, hi, 0, 0, 0, 0, 0, 0, (C.c_uint32 * 2)(0, 0), (C.c_uint32 * 2)(0, 0))
+        p6[it] = SwParams(lo, hi, 0, 0, 0, 0, 0, 0, (C.c_uint32 * 4)(0, 0, 0, 0), (C.c_uint32 * 2)(0, 0), (C.c_uint32 * 2)(0, 0))
     assert dev.swar_devtest_layers(32, N, nbr, deg.ctypes.data_as(C.c_void_p), sb.ctypes.data_as(C.c_void_p), p6, n_iter,
                                    img.ctypes.data_as(C.c_void_p)) == 0
     got = (img[:, pos].astype(np.int16) - 120).astype(np.int8).reshape(-1)
