@@ -683,6 +683,7 @@ struct LfCombiner {
     lnsfaid_group_stats* h_stats = nullptr;   /* pinned, LF_COMB_WORKERS x LF_COMB_SLOTS */
     LfSlot slots[LF_COMB_SLOTS];
     int members = 0, pending = 0;
+    char err[256] = "";              /* lnsfaid_last_hip_error text of the last failed batch (the worker's is thread-local) */
     uint64_t batches = 0, calls = 0; /* statistics (LNSFAID_TRACE at shutdown) */
     double gather_ms = 0, device_ms = 0;
 };
@@ -744,6 +745,7 @@ static void comb_run_batch(LfCombiner* cb, int w, const int* batch, int nb)
         if (rc == LNSFAID_OK) rc = stream_wait(P);
     }
     std::lock_guard<std::mutex> lk(cb->m);
+    if (rc != LNSFAID_OK) snprintf(cb->err, sizeof(cb->err), "%s", g_hip_err);
     for (int i = 0; i < nb; ++i) {
         LfSlot& s = cb->slots[batch[i]];
         s.rc = rc;
@@ -927,6 +929,7 @@ static int comb_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, int8_t* decoded
             return 1;
         }
         rc = s.rc;
+        if (rc != LNSFAID_OK) snprintf(g_hip_err, sizeof(g_hip_err), "%s", cb->err);
         if (stats) *stats = s.stats;
         s.state = LF_SLOT_IDLE;
     }
