@@ -156,6 +156,12 @@ int lnsfaid_set_cfg(lnsfaid_ctx* ctx, const lnsfaid_cfg* cfg);
  */
 int lnsfaid_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, size_t n_groups,
                    int8_t* decodedBits, lnsfaid_group_stats* stats);
+/* The reference's call shape - one group per call from T worker threads, each with its own CLDPC / context (reference
+ * CSimulate.cpp:136-164, main.cpp:164-172) - is served by a call combiner: the concurrent lnsfaid_decode calls of contexts
+ * created with max_groups == 1 on the same device and for the same code are decoded in common launches (from four such
+ * contexts on; results bit-identical to separate launches; the call still returns only when its own group is done).
+ * Environment: LNSFAID_COALESCE=0 switches it off, LNSFAID_COMB_WORKERS (1..4, default 2) sets the batches in flight,
+ * LNSFAID_SYNC=spin|block overrides how the host waits for the GPU (default: sleep from five live contexts on). */
 
 /* Same with device-resident buffers (pointers valid on the context's GPU).  Work is queued on the context's stream; the
  * call synchronises with it once per kernel launch (it reads back how many codewords are still open: 1 launch when
@@ -283,7 +289,10 @@ int lnsfaid_kernel_residency(lnsfaid_ctx* ctx, int32_t* workgroups_per_cu, int32
 
 /* Device time (HIP events on the context's stream) and launch count of the
  * decode kernel accumulated since the last reset: out_ms = total kernel
- * milliseconds, out_launches = number of kernel launches. */
+ * milliseconds, out_launches = number of kernel launches (launches queued ahead
+ * on a batch that turned out to be complete already are counted too: microseconds
+ * each).  Calls of a one-group context that went through the call combiner are
+ * not in it (they ran in launches shared with other contexts). */
 int lnsfaid_kernel_time(lnsfaid_ctx* ctx, double* out_ms, uint64_t* out_launches, int32_t reset);
 
 /* The HIP stream of the context as an opaque pointer (hipStream_t). */

@@ -585,3 +585,57 @@ def test_ef_elimination_variants_of_decode_faid(abi, lib, code50, mode):
     cfg.v2c_map_ef[0][2][5] = 7  # error-floor tables must be uniform over the weight classes for these variants
     with pytest.raises(RuntimeError):
         abi.Decoder(code50, cfg, 0, 1)
+
+
+def test_one_group_contexts_of_different_codes_and_changing_configurations(abi, lib, code50):
+    """One-group contexts share a call combiner only with contexts of the SAME code (lnsfaid_capi.hip): a context of another code
+    beside them decodes on its own, a context whose REGULAR_COL_WEIGHT is changed by lnsfaid_set_cfg (which changes the
+    bit-flipping column list of its code) leaves the common path, and a configuration change between two calls of a member is
+    picked up by its next batch.  All of it from concurrent threads, every result against the oracle / the CPU port."""
+    import threading
+    dc = _derived_code(abi, lib, [67, 68], 2)
+    n_calls = 4
+    plans = [  # (code, cfgs to cycle through)
+        (code50, [abi.default_cfg(2, 10)]),
+        (code50, [abi.default_cfg(2, 10), abi.default_cfg(2, 6)]),        # MaxIteration changes between calls
+        (code50, [abi.default_cfg(5, 10)]),
+        (code50, [abi.default_cfg(1, 10)]),
+        (dc, [abi.default_cfg(2, 10)]),                                    # another code: never in a common batch
+        (code50, [abi.default_cfg(2, 10), abi.default_cfg(2, 10)]),        # second cfg gets another column weight below
+    ]
+    plans[5][1][1].regular_col_weight = 6
+    plans[5][1][1].bf_alpha = 1
+    jobs = []
+    for t, (code, cfgs) in enumerate(plans):
+        fix = oa.synth_llr(n_calls, code.N, 3.9 if code is dc else 3.55, seed=500 + t).reshape(n_calls, -1)
+        want = []
+        for c in range(n_calls):
+            cfg = cfgs[c % len(cfgs)]
+            ref, rst = oa.decode_mt(code, cfg, np.ascontiguousarray(fix[c]), 1)
+            want.append((ref, rst))
+        jobs.append((code, cfgs, fix, want))
+    errors = []
+    start = threading.Barrier(len(jobs))
+
+    def worker(t):
+        code, cfgs, fix, want = jobs[t]
+        try:
+            dec = abi.Decoder(code, cfgs[0], device=0, max_groups=1)
+            start.wait()
+            for c in range(n_calls):
+                if len(cfgs) > 1:
+                    dec.set_cfg(cfgs[c % len(cfgs)])
+                out, st = dec.decode(np.ascontiguousarray(fix[c]), 1)
+                if not np.array_equal(out, want[c][0]) or not np.array_equal(st, want[c][1]):
+                    errors.append((t, c, st.tolist(), want[c][1].tolist()))
+            dec.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=600)
+    assert not any(th.is_alive() for th in threads), "a decode call did not return"
+    assert not errors, errors[:4]

@@ -18,16 +18,19 @@ lib = abi.load()
 code = abi.Code50GPON(lib)
 ng = 2048
 total = bad_cases = 0
-for method in (2, 5, 1, 0, 4, 3):
+# DecodeMethod 0 twice: two factors (two-rows-per-lane kernel) and one factor (four rows per lane, 16-level search)
+cases = [(2, None), (5, None), (1, None), (0, (24, 26)), (0, (24, 24)), (4, None), (3, None)]
+for method, factors in cases:
     for eb_n0 in (3.1, 3.7):
         cfg = abi.default_cfg(method, 10)
-        if method == 0:
-            cfg.factor_1, cfg.factor_2 = 24, 26
+        if factors:
+            cfg.factor_1, cfg.factor_2 = factors
         fix = oa.synth_llr(ng, code.N, eb_n0, seed=4242 + 31 * method + int(10 * eb_n0))
         d = abi.Decoder(code, cfg, 0, ng, lib)
         t0 = time.time()
         out, st = d.decode(fix, ng)
         t1 = time.time()
+        rows, store = d.rows_per_lane(), d.message_store()
         d.close()
         ref, ref_st = oa.decode_mt(code, cfg, fix, ng, kind="avx2")
         t2 = time.time()
@@ -35,8 +38,8 @@ for method in (2, 5, 1, 0, 4, 3):
         ok = bad == 0 and np.array_equal(st, ref_st)
         total += ng * 32
         bad_cases += 0 if ok else 1
-        print("method %d  %.1f dB: %d frames, %d differ, stats %s  (gpu incl. PCIe %.2f s, cpu port %.1f s, mean I/J %.2f/%.2f)"
-              % (method, eb_n0, ng * 32, bad, "equal" if np.array_equal(st, ref_st) else "DIFFER", t1 - t0, t2 - t1,
-                 st[:, 0].mean(), st[:, 1].mean()), flush=True)
-print("soak: %d frames in %d cases, %d cases with differences" % (total, 12, bad_cases))
+        print("method %d%s  %.1f dB: %d frames, %d differ, stats %s  (%d rows per lane, messages %s; gpu incl. PCIe %.2f s, cpu port %.1f s, mean I/J %.2f/%.2f)"
+              % (method, " factors %d/%d" % factors if factors else "", eb_n0, ng * 32, bad, "equal" if np.array_equal(st, ref_st) else "DIFFER",
+                 rows, {1: "in registers", 2: "through HBM"}[store], t1 - t0, t2 - t1, st[:, 0].mean(), st[:, 1].mean()), flush=True)
+print("soak: %d frames in %d cases, %d cases with differences" % (total, 2 * len(cases), bad_cases))
 sys.exit(1 if bad_cases else 0)
