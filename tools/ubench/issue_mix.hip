@@ -41,6 +41,25 @@ __global__ __launch_bounds__(64) void k(uint32_t* out, uint32_t seed)
     out[blockIdx.x * 64 + threadIdx.x] = s;
 }
 
+// one wave ALONE on its SIMD: 64 KB of LDS per single-wave workgroup, so a CU holds two of them (on two of its four SIMDs)
+template <typename K> void run_alone(K kern, const char* name, uint32_t* d, double ghz)
+{
+    const size_t lds = 65536 - 512;
+    const int rounds = 4, blocks = 256 * 2 * rounds;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, 0, d, 1u);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, 0, d, 2u);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("%-10s  1 wave alone on its SIMD (2 per CU)      %8.3f ms  %5.2f SIMD-cycles per wave-instruction\n", name, ms,
+           ms * 1e-3 * ghz * 1e9 / ((double)rounds * TRIPS * BODY));
+}
+
 template <typename K> void run(K kern, const char* name, uint32_t* d, int waves_per_simd, double ghz)
 {
     // waves per CU = 4 x waves per SIMD: dynamic LDS such that exactly that many single-wave workgroups fit (160 KB per CU)
@@ -71,7 +90,9 @@ int main()
            p.multiProcessorCount, ghz, BODY);
     uint32_t* d;
     (void)hipMalloc(&d, (size_t)256 * 4 * 8 * 4 * 64 * 4);
-    for (int w : { 2, 3, 4, 5, 8 }) { // (one wave per SIMD would need more than the 64 KB a workgroup may ask for)
+    run_alone(k<4>, "4 chains", d, ghz);
+    run_alone(k<8>, "8 chains", d, ghz);
+    for (int w : { 2, 3, 4, 5, 8 }) {
         run(k<4>, "4 chains", d, w, ghz);
         run(k<8>, "8 chains", d, w, ghz);
     }
