@@ -25,6 +25,45 @@ __device__ __forceinline__ void body(uint32_t (&a)[8], uint32_t b, uint32_t c)
     }
 }
 
+// one instruction class per kernel: what each costs at the decode kernel's residency (two waves per SIMD)
+// 0 v_add_u32 (two sources)  1 v_bitop3_b32  2 v_perm_b32  3 v_alignbyte_b32  4 v_add3_u32  5 v_and_or_b32  6 v_add_u32 with an SGPR source
+// 7 v_and_or_b32 with an SGPR source  8 v_lshlrev_b32 (inline constant)  9 v_and_b32 with a 32-bit literal
+template <int I, int OP>
+__device__ __forceinline__ void body_one(uint32_t (&a)[8], uint32_t b, uint32_t c, uint32_t sg)
+{
+    if constexpr (I < BODY) {
+        uint32_t& x = a[I % 4];
+        if constexpr (OP == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+        else if constexpr (OP == 1) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(x) : "v"(b), "v"(c));
+        else if constexpr (OP == 2) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+        else if constexpr (OP == 3) asm volatile("v_alignbyte_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+        else if constexpr (OP == 4) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+        else if constexpr (OP == 5) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+        else if constexpr (OP == 6) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "s"(sg));
+        else if constexpr (OP == 7) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "s"(sg));
+        else if constexpr (OP == 8) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x));
+        else asm volatile("v_and_b32 %0, 0x87878787, %0" : "+v"(x));
+        body_one<I + 1, OP>(a, b, c, sg);
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(64) void k_one(uint32_t* out, uint32_t seed)
+{
+    extern __shared__ uint32_t dyn[];
+    uint32_t a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = seed * (2 * i + 3) + threadIdx.x;
+    uint32_t b = seed * 31 + 1, c = seed ^ 0x12345;
+    const uint32_t sg = seed * 7;
+    for (int r = 0; r < TRIPS; ++r) body_one<0, OP>(a, b, c, sg);
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s ^= a[i];
+    if (dyn[0] == 0x12345678u) s ^= 1;
+    out[blockIdx.x * 64 + threadIdx.x] = s;
+}
+
 template <int CHAINS>
 __global__ __launch_bounds__(64) void k(uint32_t* out, uint32_t seed)
 {
@@ -96,5 +135,21 @@ int main()
         run(k<4>, "4 chains", d, w, ghz);
         run(k<8>, "8 chains", d, w, ghz);
     }
+    printf("one instruction class per kernel, four chains:\n");
+    for (int w : { 2, 8 }) {
+        run(k_one<0>, "add", d, w, ghz);
+        run(k_one<8>, "shl imm", d, w, ghz);
+        run(k_one<9>, "and lit", d, w, ghz);
+        run(k_one<1>, "bitop3", d, w, ghz);
+        run(k_one<2>, "perm", d, w, ghz);
+        run(k_one<3>, "alignbyte", d, w, ghz);
+        run(k_one<4>, "add3", d, w, ghz);
+        run(k_one<5>, "and_or", d, w, ghz);
+        run(k_one<6>, "add sgpr", d, w, ghz);
+        run(k_one<7>, "and_or sg", d, w, ghz);
+    }
+    run_alone(k_one<0>, "add", d, ghz);
+    run_alone(k_one<1>, "bitop3", d, ghz);
+    run_alone(k_one<2>, "perm", d, ghz);
     return 0;
 }
