@@ -284,33 +284,38 @@ def worker(args):
     # barrier, the MAX over the ranks' times and the gather of per-rank lines.  Ranks that share a GPU (--share-gpu rehearsal)
     # and the CPU self-test cannot form an RCCL communicator (one rank per device) and sum over gloo; N = 1 has nothing to sum.
     reduce_via = "none (world size 1: no collective)"
-    if world > 1 and not selftest and backend == "nccl":
+    if dist is not None and backend == "nccl" and not selftest:
+        # (also for a world of one under the launcher: still the product's RCCL path, on a communicator of one rank)
         import ctypes
-        cid = (ctypes.c_uint8 * 128)()
-        if rank == 0:
-            rc = lib.lnsfaid_comm_unique_id(cid)
-            if rc != 0:
-                raise SystemExit("lnsfaid_comm_unique_id failed: %d" % rc)
-        box = [bytes(cid) if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        cid = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
-        dec.comm_init(world, rank, cid)
-        reduce_via = "lnsfaid_allreduce_counters"
+        ok, why = 1, ""
+        try:
+            cid = (ctypes.c_uint8 * 128)()
+            if rank == 0:
+                rc = lib.lnsfaid_comm_unique_id(cid)
+                if rc != 0:
+                    raise RuntimeError("lnsfaid_comm_unique_id: %d" % rc)
+            if world > 1:
+                box = [bytes(cid) if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                cid = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+            dec.comm_init(world, rank, cid)
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, repr(e)
+        # every rank must take the same path: agree over the torch process group
+        flag = torch.tensor([ok], dtype=torch.int32, device=red_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            reduce_via = "lnsfaid_allreduce_counters"
+        else:
+            lib.lnsfaid_comm_destroy(dec.ctx)
+            reduce_via = "torch.distributed nccl (lnsfaid_comm_init failed on some rank%s)" % (": " + why if why else "")
     elif dist is not None and world > 1:
         reduce_via = "torch.distributed gloo"
-    elif dist is not None and backend == "nccl" and not selftest:
-        # world of one under the launcher: still the product's RCCL path, on a communicator of one rank
-        import ctypes
-        cid = (ctypes.c_uint8 * 128)()
-        if lib.lnsfaid_comm_unique_id(cid) != 0:
-            raise SystemExit("lnsfaid_comm_unique_id failed")
-        dec.comm_init(1, 0, cid)
-        reduce_via = "lnsfaid_allreduce_counters"
 
     def reduce_counters(local):
         if reduce_via == "lnsfaid_allreduce_counters":
             return [int(c) for c in dec.allreduce_counters(local)]
-        if reduce_via == "torch.distributed gloo":
+        if reduce_via.startswith("torch.distributed"):
             return lnsfaid_dist.allreduce_counters(local, dist, red_device)
         return [int(c) for c in local]
 
