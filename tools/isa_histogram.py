@@ -3,7 +3,7 @@
 
 usage: isa_histogram.py <file.s> [kernel-name-substring] [--blocks N]
 Classes (tools/ubench/valu_rate.hip, tools/ubench/issue_mix.hip, profiles/*/ubench_*.txt): a wave64 VALU instruction issues in 2 cycles
-("full") unless it is a shift, a packed 16-bit operation, a three-source VOP3 other than v_bitop3_b32, an integer
+("full") unless it is a LEFT shift, a packed 16-bit operation, a three-source VOP3 other than v_bitop3_b32, an integer
 multiply, a dot product, or reads an SGPR operand ("half", 4 cycles).  Prints the largest blocks of the kernel with their
 instruction counts per class and the weighted issue cycles.
 """
@@ -12,9 +12,9 @@ import json
 import re
 import sys
 
-# 32-bit shifts belong to the half-rate class too (tools/ubench/issue_mix.hip, profiles/r03/ubench_issue_mix_vs_occupancy.txt: v_lshlrev_b32
-# with an inline constant 4.05 SIMD cycles per wave64 instruction at 8 waves per SIMD, like v_perm_b32; v_add_u32 / v_and_b32 / v_bitop3_b32 2.1 - 2.2)
-HALF_MNEMONICS = ("v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_pk_", "v_perm_b32", "v_and_or_b32", "v_lshl_or_b32", "v_or3_b32", "v_bfi_b32", "v_bfe_", "v_med3", "v_min3", "v_max3",
+# LEFT shifts belong to the half-rate class (tools/ubench/issue_mix.hip, profiles/r03/ubench_issue_mix_vs_occupancy.txt: v_lshlrev_b32 by 1, by 8
+# or by a register 4.05 SIMD cycles per wave64 instruction at 8 waves per SIMD, like v_perm_b32; v_lshrrev_b32, v_add_u32, v_and_b32, v_bitop3_b32 2.1 - 2.2)
+HALF_MNEMONICS = ("v_lshlrev_b32", "v_pk_", "v_perm_b32", "v_and_or_b32", "v_lshl_or_b32", "v_or3_b32", "v_bfi_b32", "v_bfe_", "v_med3", "v_min3", "v_max3",
                   "v_alignbit_b32", "v_alignbyte_b32", "v_mad_", "v_mul_lo", "v_mul_hi", "v_dot", "v_lshlrev_b64", "v_lshrrev_b64",
                   "v_ashrrev_i64", "v_add3_u32", "v_lshl_add_u32", "v_add_lshl_u32", "v_xad_u32", "v_sad_", "v_fma", "v_mul_u32_u24", "v_mul_i32_i24",
                   "v_cndmask_b32", "v_readlane", "v_writelane", "v_readfirstlane")

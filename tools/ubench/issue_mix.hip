@@ -28,6 +28,8 @@ __device__ __forceinline__ void body(uint32_t (&a)[8], uint32_t b, uint32_t c)
 // one instruction class per kernel: what each costs at the decode kernel's residency (two waves per SIMD)
 // 0 v_add_u32 (two sources)  1 v_bitop3_b32  2 v_perm_b32  3 v_alignbyte_b32  4 v_add3_u32  5 v_and_or_b32  6 v_add_u32 with an SGPR source
 // 7 v_and_or_b32 with an SGPR source  8 v_lshlrev_b32 (inline constant)  9 v_and_b32 with a 32-bit literal
+// 10 v_mov_b32_sdwa (byte 1 of the source)  11 v_or_b32_sdwa (byte 0 of one source)  12 the same with an SGPR source  13 v_lshrrev_b32 by 8
+// 14 v_lshlrev_b32 by 8  15 v_lshrrev_b32 by 1  16 / 17 the shifts by a register  18 v_sub_u32
 template <int I, int OP>
 __device__ __forceinline__ void body_one(uint32_t (&a)[8], uint32_t b, uint32_t c, uint32_t sg)
 {
@@ -42,6 +44,15 @@ __device__ __forceinline__ void body_one(uint32_t (&a)[8], uint32_t b, uint32_t 
         else if constexpr (OP == 6) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "s"(sg));
         else if constexpr (OP == 7) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "s"(sg));
         else if constexpr (OP == 8) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x));
+        else if constexpr (OP == 10) asm volatile("v_mov_b32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "+v"(x));
+        else if constexpr (OP == 11) asm volatile("v_or_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "+v"(x) : "v"(b));
+        else if constexpr (OP == 12) asm volatile("v_or_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "+v"(x) : "s"(sg));
+        else if constexpr (OP == 13) asm volatile("v_lshrrev_b32 %0, 8, %0" : "+v"(x));
+        else if constexpr (OP == 14) asm volatile("v_lshlrev_b32 %0, 8, %0" : "+v"(x));
+        else if constexpr (OP == 15) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(x));
+        else if constexpr (OP == 16) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(x) : "v"(b));
+        else if constexpr (OP == 17) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(x) : "v"(b));
+        else if constexpr (OP == 18) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(b));
         else asm volatile("v_and_b32 %0, 0x87878787, %0" : "+v"(x));
         body_one<I + 1, OP>(a, b, c, sg);
     }
@@ -138,7 +149,7 @@ int main()
     printf("one instruction class per kernel, four chains:\n");
     for (int w : { 2, 8 }) {
         run(k_one<0>, "add", d, w, ghz);
-        run(k_one<8>, "shl imm", d, w, ghz);
+        run(k_one<8>, "shl 1", d, w, ghz);
         run(k_one<9>, "and lit", d, w, ghz);
         run(k_one<1>, "bitop3", d, w, ghz);
         run(k_one<2>, "perm", d, w, ghz);
@@ -147,6 +158,15 @@ int main()
         run(k_one<5>, "and_or", d, w, ghz);
         run(k_one<6>, "add sgpr", d, w, ghz);
         run(k_one<7>, "and_or sg", d, w, ghz);
+        run(k_one<13>, "shr 8", d, w, ghz);
+        run(k_one<14>, "shl 8", d, w, ghz);
+        run(k_one<15>, "shr 1", d, w, ghz);
+        run(k_one<16>, "shl vgpr", d, w, ghz);
+        run(k_one<17>, "shr vgpr", d, w, ghz);
+        run(k_one<18>, "sub", d, w, ghz);
+        run(k_one<10>, "mov sdwa", d, w, ghz);
+        run(k_one<11>, "or sdwa", d, w, ghz);
+        run(k_one<12>, "or sdwa sg", d, w, ghz);
     }
     run_alone(k_one<0>, "add", d, ghz);
     run_alone(k_one<1>, "bitop3", d, ghz);
