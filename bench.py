@@ -66,7 +66,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # occupies its SIMD for 2 cycles at the full rate
 N_SIMD, CLOCK_GHZ, CYCLES_PER_WAVE64_VALU = 1024, 2.4, 2
 VALU_PEAK_GINSTR = N_SIMD * CLOCK_GHZ / CYCLES_PER_WAVE64_VALU
-KERNEL_SOURCES = ["lnsfaid_kernel4.hip", "lnsfaid_swar.h", "lnsfaid_phases.h", "lnsfaid_kernels.hip", "lnsfaid_device.h", "Makefile"]
+KERNEL_SOURCES = ["lnsfaid_kernel4.hip", "lnsfaid_rows4.h", "lnsfaid_swar.h", "lnsfaid_phases.h", "lnsfaid_kernels.hip", "lnsfaid_device.h", "Makefile"]
 
 
 def kernel_source_hash():
@@ -106,8 +106,10 @@ def synth_llr(torch, device, n_groups, eb_n0, seed, mod_type=2, scale=13.0):
     return out
 
 
-def kernel_instance_name(method, rows_per_lane, message_store, pyabi):
+def kernel_instance_name(method, rows_per_lane, message_store, pyabi, waves=1):
     """The template instance a context launches, as rocprofv3 prints it (what the counter files under profiles/ are keyed on)."""
+    if waves == 2:
+        return "void lnsfaid_decode5_kernel<%d>(LfKernelArgs)" % method
     if rows_per_lane == 4:
         return "void lnsfaid_decode4_kernel<%d, %s, false>(LfKernelArgs)" % (method, "true" if message_store == pyabi.MSG_REGISTERS else "false")
     return "void lnsfaid_decode_kernel<%d, true>(LfKernelArgs)" % method
@@ -379,7 +381,8 @@ def worker(args):
                     mean_I=float(stats[:, 0].mean()), mean_J=float(stats[:, 1].mean()), counters=totals,
                     per_rank_counters=per_rank, per_rank_ms=per_rank_ms, n_groups=n_groups,
                     rows_per_lane=(0 if selftest else dec.rows_per_lane()),
-                    message_store=(0 if selftest else dec.message_store()))
+                    message_store=(0 if selftest else dec.message_store()),
+                    waves=(1 if selftest else dec.kernel_waves()))
 
     # ---- weak leg = headline ---------------------------------------------------------------------------------------
     n_groups = args.groups
@@ -399,7 +402,7 @@ def worker(args):
     # EXTRA experiment flags in lnsfaid_version) and the headline WORKLOAD (incl. the quantiser scale).
     here_hash = kernel_source_hash()
     library = "selftest" if selftest else lib.lnsfaid_version().decode()
-    kernel_name = None if selftest else kernel_instance_name(args.method, head["rows_per_lane"], head["message_store"], pyabi)
+    kernel_name = None if selftest else kernel_instance_name(args.method, head["rows_per_lane"], head["message_store"], pyabi, head["waves"])
     valu_inst, valu_src, valu_half_frac = None, None, None
     vpath = os.path.join(ROOT, "profiles", "valu_issue_per_launch.json")
     headline_workload = (args.method == 2 and abs(args.eb_n0 - 3.0) < 1e-6 and args.groups == 2048 and args.max_iter == 10
@@ -475,7 +478,9 @@ def worker(args):
             "unit": "G wave64 VALU instructions/s",
             "frac": round(ach_ginstr / VALU_PEAK_GINSTR, 4) if ach_ginstr else None,
             "traffic": traffic,
-            "kernel": ("lnsfaid_decode4_kernel<%d, %s> (one wave per codeword, four check rows per lane, compressed messages %s)"
+            "kernel": ("lnsfaid_decode5_kernel<%d> (EXPERIMENTAL: two waves per codeword, four check rows per lane, compressed messages streamed through HBM)"
+                       % args.method) if head["waves"] == 2
+                      else ("lnsfaid_decode4_kernel<%d, %s> (one wave per codeword, four check rows per lane, compressed messages %s)"
                        % (args.method, "true, false" if head["message_store"] == 1 else "false, false",
                           "in registers" if head["message_store"] == 1 else "streamed through HBM")) if head["rows_per_lane"] == 4
                       else "lnsfaid_decode_kernel<%d> (128 threads per codeword, two check rows per lane)" % args.method,

@@ -267,6 +267,14 @@ int lnsfaid_allreduce_counters(lnsfaid_ctx* ctx, uint64_t counters[4]);
 int lnsfaid_select_kernel(lnsfaid_ctx* ctx, int32_t rows_per_lane);
 int lnsfaid_kernel_rows_per_lane(const lnsfaid_ctx* ctx);
 
+/* EXPERIMENTAL.  Wavefronts per codeword of the four-rows-per-lane kernel: 1 (default; 0 selects the default) or 2
+ * (lnsfaid_kernel5.hip: the edges of a layer are dealt to two waves, four waves per SIMD instead of two; DecodeMethods 1..5
+ * without the erasing EF_ELIMINATION 2, messages streamed through HBM).  Results are identical; LNSFAID_E_INVAL where it does
+ * not apply.  Environment: LNSFAID_WAVES_PER_CODEWORD=2 forces it for every context it applies to.  lnsfaid_kernel_waves
+ * returns what the next decode will launch. */
+int lnsfaid_select_waves(lnsfaid_ctx* ctx, int32_t waves_per_codeword);
+int lnsfaid_kernel_waves(const lnsfaid_ctx* ctx);
+
 /* Where the four-rows-per-lane kernel keeps the check-to-variable messages (the reference's var_msgs, CLDPC.h:123,
  * lifetime CDecoder_FAID.cpp:211-214 ... :923) between the layers of a launch.  LNSFAID_MSG_REGISTERS: the compressed messages
  * of the codeword (72 dwords per lane for the 12 layers of the 50G-PON code) stay in the wavefront's registers for the whole

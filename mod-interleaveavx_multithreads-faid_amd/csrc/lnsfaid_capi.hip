@@ -27,6 +27,9 @@ extern "C" const void* lf_decode4_func(int method, int ef, int rm);
 extern "C" int lf_decode4_threads(void);
 extern "C" hipError_t lf_launch_decode4(int method, int ef, int rm, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream);
 extern "C" int lf_decode4_rm_layers(void);
+extern "C" const void* lf_decode5_func(int method);
+extern "C" int lf_decode5_threads(void);
+extern "C" hipError_t lf_launch_decode5(int method, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t lf_launch_count_errors(const int8_t* decoded, const int8_t* input_bits, int n_var, int k_info,
                                              size_t n_cw, unsigned long long* out, hipStream_t stream);
 
@@ -102,6 +105,7 @@ struct lnsfaid_ctx {
     int8_t* d_io_out = nullptr;
     lnsfaid_group_stats* d_io_stats = nullptr;
     int rows_per_lane = 0; /* 0: pick per configuration; 2 / 4: forced (lnsfaid_select_kernel) */
+    int waves_per_cw = 0;  /* 0 / 1: one wave per codeword; 2: lnsfaid_kernel5.hip where it applies (lnsfaid_select_waves) */
     int msg_store = 0;     /* 0: pick per code; 1: registers; 2: streamed through HBM (lnsfaid_select_message_store) */
     struct LfCombiner* comb = nullptr; /* call combiner this one-group context is a member of (see below) */
     int comb_slot = -1;
@@ -395,6 +399,8 @@ extern "C" int lnsfaid_create(lnsfaid_ctx** out, const lnsfaid_code* code, const
     ctx->max_groups = max_groups;
     if (const char* e = getenv("LNSFAID_ROWS_PER_LANE")) /* test / A-B switch: force the 2-rows-per-lane kernel for a whole run */
         ctx->rows_per_lane = (e[0] == '2') ? 2 : 0;
+    if (const char* e = getenv("LNSFAID_WAVES_PER_CODEWORD")) /* test / A-B switch, see lnsfaid_select_waves */
+        ctx->waves_per_cw = (e[0] == '2') ? 2 : 0;
     if (const char* e = getenv("LNSFAID_MSG_STORE")) /* test / A-B switch, see lnsfaid_select_message_store */
         ctx->msg_store = (e[0] == 'h') ? LNSFAID_MSG_HBM : ((e[0] == 'r') ? LNSFAID_MSG_REGISTERS : 0);
     g_live_contexts.fetch_add(1, std::memory_order_relaxed); /* (lnsfaid_destroy takes it back) */
@@ -465,6 +471,25 @@ extern "C" int lnsfaid_select_kernel(lnsfaid_ctx* ctx, int32_t rows_per_lane)
 
 extern "C" int lnsfaid_kernel_rows_per_lane(const lnsfaid_ctx* ctx) { return ctx ? (use_kernel4(ctx) ? 4 : 2) : LNSFAID_E_INVAL; }
 
+/* Two wavefronts per codeword (lnsfaid_kernel5.hip): the four-rows kernel's configurations without DecodeMethod 0 and without the
+ * erasing instance of EF_ELIMINATION 2; messages streamed through HBM. */
+static bool kernel5_possible(const lnsfaid_ctx* ctx)
+{
+    const int m = ctx->hcfg.method;
+    return kernel4_possible(ctx) && m >= 1 && m <= 5 && !(m == 2 && ctx->hcfg.ef == 2);
+}
+static bool use_kernel5(const lnsfaid_ctx* ctx) { return ctx->waves_per_cw == 2 && use_kernel4(ctx) && kernel5_possible(ctx); }
+
+extern "C" int lnsfaid_select_waves(lnsfaid_ctx* ctx, int32_t waves_per_codeword)
+{
+    if (!ctx || waves_per_codeword < 0 || waves_per_codeword > 2) return LNSFAID_E_INVAL;
+    if (waves_per_codeword == 2 && !(use_kernel4(ctx) && kernel5_possible(ctx))) return LNSFAID_E_INVAL;
+    ctx->waves_per_cw = waves_per_codeword;
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_kernel_waves(const lnsfaid_ctx* ctx) { return ctx ? (use_kernel5(ctx) ? 2 : 1) : LNSFAID_E_INVAL; }
+
 /* Where the four-rows kernel keeps the compressed check-to-variable messages between layers: in registers (codes of up to
  * lf_decode4_rm_layers() layers; not built for the erasing instance of EF_ELIMINATION 2) or streamed through HBM. */
 static bool msg_registers_possible(const lnsfaid_ctx* ctx)
@@ -474,12 +499,16 @@ static bool msg_registers_possible(const lnsfaid_ctx* ctx)
 }
 static bool use_msg_registers(const lnsfaid_ctx* ctx)
 {
-    if (!msg_registers_possible(ctx)) return false;
+    if (!msg_registers_possible(ctx) || use_kernel5(ctx)) return false;
     return ctx->msg_store != LNSFAID_MSG_HBM;
 }
 
 static const void* selected_kernel(const lnsfaid_ctx* ctx, int* threads)
 {
+    if (use_kernel5(ctx)) {
+        *threads = lf_decode5_threads();
+        return lf_decode5_func(ctx->hcfg.method);
+    }
     if (use_kernel4(ctx)) {
         *threads = lf_decode4_threads();
         return lf_decode4_func(ctx->hcfg.method, ctx->hcfg.ef, use_msg_registers(ctx) ? 1 : 0);
@@ -606,7 +635,8 @@ static int decode_device_impl(lnsfaid_ctx* ctx, const int8_t* d_fixInput, size_t
             a.status_next = ctx->d_status[cur ^ 1];
             a.remaining = ctx->d_remaining + j;
             HIP_TRY(hipEventRecord(ctx->ev_chain[j], ctx->stream));
-            if (use_kernel4(ctx)) HIP_TRY(lf_launch_decode4(ctx->hcfg.method, ctx->hcfg.ef, use_msg_registers(ctx) ? 1 : 0, &a, ctx->lds_bytes, ctx->stream));
+            if (use_kernel5(ctx)) HIP_TRY(lf_launch_decode5(ctx->hcfg.method, &a, ctx->lds_bytes, ctx->stream));
+            else if (use_kernel4(ctx)) HIP_TRY(lf_launch_decode4(ctx->hcfg.method, ctx->hcfg.ef, use_msg_registers(ctx) ? 1 : 0, &a, ctx->lds_bytes, ctx->stream));
             else HIP_TRY(lf_launch_decode(ctx->hcfg.method, ctx->hcfg.uniform_w, &a, ctx->lds_bytes, ctx->stream));
             cur ^= 1;
         }
@@ -906,7 +936,7 @@ static void comb_leave(lnsfaid_ctx* ctx, int slot)
 /* 1: decoded through the combiner (*rc_out = result); 0: not applicable now, take the direct path */
 static int comb_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, int8_t* decodedBits, lnsfaid_group_stats* stats, int* rc_out)
 {
-    if (ctx->comb_slot < 0 || ctx->rows_per_lane != 0 || ctx->msg_store != 0) return 0;
+    if (ctx->comb_slot < 0 || ctx->rows_per_lane != 0 || ctx->msg_store != 0 || ctx->waves_per_cw != 0) return 0;
     LfCombiner* cb = ctx->comb;
     const int slot = ctx->comb_slot;
     {

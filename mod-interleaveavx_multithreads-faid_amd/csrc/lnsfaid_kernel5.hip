@@ -1,57 +1,53 @@
 /*
- * lnsfaid_kernel4.hip — the decode kernel with ONE wavefront per codeword and four check rows per lane (gfx950).
+ * lnsfaid_kernel5.hip - the four-rows-per-lane decode kernel with TWO wavefronts per codeword (gfx950).  EXPERIMENTAL and opt-in
+ * (lnsfaid_select_waves(ctx, 2) / LNSFAID_WAVES_PER_CODEWORD=2); bit-exact with lnsfaid_kernel4.hip, and SLOWER: 14.85 ms against
+ * 13.37 ms per launch of the headline batch (profiles/r03_two_waves/).  Kept because it is the measurement that
+ * closes the "more waves per SIMD" question for this decoder, with the split layer step it needs (lnsfaid_swar.h, WAVES = 2).
  *
- * Same decoder, same group-of-32 protocol, same HBM state as lnsfaid_kernels.hip (see its header for the decision-point time
- * line and the park / relaunch rules); what differs is how a layer is computed:
- *   - lane i owns rows i, i + 64, i + 128, i + 192 of every layer; byte k of a working register belongs to row i + 64 k and
- *     the layer step is carry-free byte-parallel arithmetic on plain 32-bit operations (lnsfaid_swar.h) instead of two rows on
- *     packed 16-bit operations: 928 VALU instructions per layer of 256 rows, 70 % of them of the full-rate class, against
- *     2 x 615 with three quarters of the half-rate class;
- *   - En is kept in LDS interleaved (variable node v of a block column in dword v mod 64, byte v div 64, biased by 120), so an
- *     edge is one ds_read_b32 + one byte rotation for four rows, and a workgroup is a single wave: no barrier between layers;
- *   - the compressed messages of a lane's four rows are 24 bytes per layer (SwRow).
- * One wave per codeword means two waves per SIMD (the LDS image of a codeword allows 8 per CU), and with two waves nothing hides a
- * stall: every loop that loads keeps all its loads in flight before the first use, the walk tables of the bit-flipping stage live in
- * registers, and everything on the hot path is inlined (tests/test_kernel_isa.py holds these properties).
- * Used for DecodeMethods 1..5 whenever the FAID tables are uniform over the weight classes and non-decreasing (every shipped
- * set) and for DecodeMethod 0 with one normalisation factor >= 15; other tables / factors run on the two-rows-per-lane kernel.
+ * Same decoder, protocol, HBM state and LDS image as lnsfaid_kernel4.hip.  The LDS image of a codeword allows 8 codewords per CU;
+ * with one wave each that is two waves per SIMD.  Here a workgroup is 128 threads: wave 0 is the kernel of lnsfaid_kernel4.hip
+ * (staging, syndromes, bit flipping, park / resume, output - everything that is not a layered iteration), and inside a layered
+ * iteration the layer's edges are dealt to the two waves by the parity of their index (sw_layer_step<..., WAVES = 2>): four
+ * waves per SIMD, 128 registers per wave, the compressed messages streamed through HBM.  Wave 1 sleeps at a barrier whenever
+ * wave 0 is outside the layer loop.  DecodeMethods 1..5 without the erasing EF_ELIMINATION 2.
  */
 #include <hip/hip_runtime.h>
 
+/* Wave 0 runs the single-wave phases of lnsfaid_kernel4.hip / lnsfaid_phases.h on its own: their __syncthreads() (a no-op
+ * barrier plus an LDS fence in a one-wave workgroup) must not become an s_barrier that waits for wave 1. */
+__device__ __forceinline__ void lf5_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+#define __syncthreads() lf5_wave_sync()
+/* both waves of the workgroup */
+__device__ __forceinline__ void lf5_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 #include "lnsfaid_rows4.h"
 
-/* ---- the compressed messages of the codeword on chip (RM instances) ------------------------------------------------
- * A lane's four rows are 6 dwords per layer (SwRow), 72 per codeword for the 12 layers of the 50G-PON code: they stay in
- * registers for the whole launch, field f of layer br in element br of vector f.  The layer number is wave-uniform, so an
- * access is one v_mov_b32 under s_set_gpr_idx_on (no scratch, no waterfall).  Codes with more than LF4_RM_LAYERS layers
- * stream the messages through HBM one layer ahead of use (the !RM instances). */
-#define LF4_RM_LAYERS 12
-static_assert(LF4_RM_LAYERS * 16 <= LF_SYN_ROUNDS * 64, "the RM instances assume that the syndrome walk tables fit the register cache");
-typedef uint32_t lf4_vec __attribute__((ext_vector_type(LF4_RM_LAYERS)));
-struct SwRegs {
-    lf4_vec x0, x1, x2, cw, pa0, pa1;
+/* exchange area of the two waves: the hard-decision plane's LDS, dead between the syndrome stage and the next one; slot k of
+ * lane i at word k * 64 + i */
+struct Xch5 {
+    uint32_t base; /* LDS byte offset + 4 * lane */
+    __device__ __forceinline__ void put(int k, uint32_t v) const { lds4_wr(base + 256u * (uint32_t)k, v); }
+    __device__ __forceinline__ uint32_t get(int k) const { return lds4_rd(base + 256u * (uint32_t)k); }
+    __device__ __forceinline__ void barrier() const { lf5_barrier(); }
 };
-__device__ __forceinline__ SwRow regs_get(const SwRegs& R, int br)
-{
-    SwRow r;
-    r.x[0] = R.x0[br]; r.x[1] = R.x1[br]; r.x[2] = R.x2[br]; r.cw = R.cw[br]; r.pa[0] = R.pa0[br]; r.pa[1] = R.pa1[br];
-    return r;
-}
-__device__ __forceinline__ void regs_put(SwRegs& R, int br, const SwRow& r)
-{
-    R.x0[br] = r.x[0]; R.x1[br] = r.x[1]; R.x2[br] = r.x[2]; R.cw[br] = r.cw; R.pa0[br] = r.pa[0]; R.pa1[br] = r.pa[1];
-}
+#define LF5_CMD_SLOT 5 /* reduction-scratch word through which role 0 tells role 1 what to do next: 0 = the kernel ends, else the
+                        * number of the layered iteration to run */
 
-/* ---- one layered iteration (lnsfaid_swar.h does the rows) ---- */
-template <int METHOD, bool ERA, bool RM>
-__device__ __forceinline__ void main_step4(CCode c, CCfg f, const LfDevCode* gc, SwRow* __restrict__ rows, SwRegs& R, int lane, int it, const uint32_t* sP,
-                           bool have_par, bool lme, uint32_t era_plane)
+/* ---- one layered iteration, both waves (lnsfaid_swar.h does the rows) ---- */
+template <int METHOD, int WAVE>
+__device__ __forceinline__ void main_step5(CCode c, CCfg f, const LfDevCode* gc, SwRow* __restrict__ rows, int lane, int it, const uint32_t* sP,
+                           bool have_par, bool lme, uint32_t xch_base)
 {
-    /* register constants of the layer step: built per iteration (17 moves), outside the layer loop and the per-degree instances,
-     * and dead again before the syndrome stage - kept alive across it they are spilled (they come from asm statements, which
-     * the compiler cannot rematerialise) */
-    it = __builtin_amdgcn_readfirstlane(it); /* uniform, and the compiler must know it: a divergent iteration number turns the
-                                              * scalar branches and table loads of every layer into masked / per-lane ones */
+    it = __builtin_amdgcn_readfirstlane(it);
     const SwK K = sw_consts((uint32_t)it);
     const bool fresh = (it == 1); /* no iteration has run yet: every Lmn is still 0, nothing in HBM */
     const int rem = f->max_iter - it;
@@ -62,58 +58,23 @@ __device__ __forceinline__ void main_step4(CCode c, CCfg f, const LfDevCode* gc,
     p.f1 = f->factor_1; p.f2 = f->factor_2;
     p.window = rem <= f->floor_iter_thresh;
     p.ef_tables = f->ef >= 1;
-    if (LF4_OMS(METHOD)) sw_oms_tables(p); /* uniform: scalar work, once per iteration */
-    if (METHOD == 0) { p.nms_t[0] = f->nms_t[0]; p.nms_t[1] = f->nms_t[1]; p.nms_t[2] = f->nms_t[2]; p.nms_t[3] = f->nms_t[3]; }
+    if (LF4_OMS(METHOD)) sw_oms_tables(p);
     const int nbr = c->nbr;
     const SwLds lds = SwLds();
-    const SwRow zero = { { 0u, 0u, 0u }, 0u, { 0u, 0u } }; /* Lmn = 0 before the first iteration (CDecoder_FAID.cpp:211-214) */
-    if (RM) {
-        /* messages in registers: no vector memory operation inside the layer loop (the registers hold zeros before the first
-         * iteration: the kernel clears them when it stages a fresh codeword) */
-        uint32_t tabv = gc->sbplain[0][lane & 31];
-#pragma nounroll
-        for (int br = 0; br < nbr; ++br) {
-            const int brn = br + 1 < nbr ? br + 1 : 0;
-            const uint32_t tabn = gc->sbplain[brn][lane & 31]; /* next layer's edge table, a layer ahead of its use */
-            const int deg = c->deg[br];
-            uint32_t rowpar = 0;
-            if (have_par) { /* syndrome bits of rows lane + 64 k of this layer as byte masks */
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t wv = sP[br * 8 + 2 * k + (lane >> 5)];
-                    rowpar |= ((wv >> (lane & 31)) & 1u) ? (0xffu << (8 * k)) : 0u;
-                }
-            }
-            DevTab4 tab;
-            tab.c = c; tab.br = br; tab.sbv = tabv;
-            const SwRow cur = regs_get(R, br);
-            SwRow st;
-            const uint32_t era_edges = ERA ? c->era_edges[br] : 0u;
-            if (ERA) st = sw_layer_step<METHOD, 0, ERA>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme, era_edges, era_plane); /* rare: one instance */
-            else if (deg == 23) st = sw_layer_step<METHOD, 23>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
-            else if (deg == 22) st = sw_layer_step<METHOD, 22>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
-            else st = sw_layer_step<METHOD, 0>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
-            regs_put(R, br, st);
-            tabv = tabn;
-        }
-        return;
-    }
+    Xch5 xch;
+    xch.base = xch_base + 4u * (uint32_t)lane;
+    const SwRow zero = { { 0u, 0u, 0u }, 0u, { 0u, 0u } };
     SwRow cur = zero;
     if (!fresh) cur = rows[lane];
-    uint32_t tabv = gc->sbplain[0][lane & 31];
-    /* Nothing may be in flight when the layer loop is entered: the compiler merges the counter state of this path into the
-     * loop header, and with loads pending here it waits in front of every layer as if they still were - in steady state that
-     * is a wait for the row store issued a few instructions earlier (a memory round trip per layer). */
-    __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0) */
+    uint32_t tabv = WAVE == 0 ? gc->sbplain[0][lane & 31] : 0u;
+    __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0): nothing in flight when the layer loop is entered (lnsfaid_kernel4.hip) */
     for (int br = 0; br < nbr; ++br) {
-        /* next layer's messages and edge table: issued a whole layer ahead of their use; always a valid address (the last
-         * layer re-reads layer 0, the first iteration reads what it is about to overwrite and ignores it) */
         const int brn = br + 1 < nbr ? br + 1 : 0;
-        const SwRow nxt = rows[brn * LF_T4 + lane];
-        const uint32_t tabn = gc->sbplain[brn][lane & 31];
-        const int deg = c->deg[br]; /* (a bit mask over the layers instead of this scalar load was measured: 1 % slower) */
+        const SwRow nxt = rows[brn * LF_T4 + lane]; /* (both waves read the record: wave 1 needs the sign words and the magnitudes) */
+        const uint32_t tabn = WAVE == 0 ? gc->sbplain[brn][lane & 31] : 0u;
+        const int deg = c->deg[br];
         uint32_t rowpar = 0;
-        if (have_par) { /* syndrome bits of rows lane + 64 k of this layer as byte masks */
+        if (have_par && WAVE == 0) { /* syndrome bits of rows lane + 64 k of this layer as byte masks (wave 0 forms the magnitudes) */
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t wv = sP[br * 8 + 2 * k + (lane >> 5)];
@@ -123,51 +84,26 @@ __device__ __forceinline__ void main_step4(CCode c, CCfg f, const LfDevCode* gc,
         DevTab4 tab;
         tab.c = c; tab.br = br; tab.sbv = tabv;
         SwRow st;
-        const uint32_t era_edges = ERA ? c->era_edges[br] : 0u;
-        if (ERA) st = sw_layer_step<METHOD, 0, ERA>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme, era_edges, era_plane); /* rare: one instance */
-        else if (deg == 23) st = sw_layer_step<METHOD, 23>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
-        else if (deg == 22) st = sw_layer_step<METHOD, 22>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
-        else st = sw_layer_step<METHOD, 0>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme);
-        /* take the prefetched data BEFORE the store is issued: vector-memory operations retire in order, so a wait for these
-         * loads placed after the store would also wait for the store's round trip, once per layer */
+        if (deg == 23) st = sw_layer_step<METHOD, 23, false, 2, WAVE>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme, 0u, 0u, xch);
+        else if (deg == 22) st = sw_layer_step<METHOD, 22, false, 2, WAVE>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme, 0u, 0u, xch);
+        else st = sw_layer_step<METHOD, 0, false, 2, WAVE>(lds, tab, p, K, (uint32_t)lane, deg, cur, fresh, rowpar, lme, 0u, 0u, xch);
         cur = fresh ? zero : nxt;
         tabv = tabn;
         asm volatile("" : "+v"(cur.x[0]), "+v"(cur.x[1]), "+v"(cur.x[2]), "+v"(cur.cw), "+v"(cur.pa[0]), "+v"(cur.pa[1]), "+v"(tabv));
         __builtin_amdgcn_sched_barrier(0);
-        if (rem > 0) rows[br * LF_T4 + lane] = st; /* the last layered iteration's messages are never read again */
+        if (WAVE == 0 && rem > 0) rows[br * LF_T4 + lane] = st; /* the last layered iteration's messages are never read again */
     }
+    /* the record stores of the last layers must be visible to wave 1's loads of the next iteration: the barrier in front of the
+     * next iteration (command hand-over) follows a release fence, and both waves of a workgroup share the CU's caches */
 }
 
-/* messages of a parking / resuming codeword between the registers and its slot in HBM (RM instances): every layer's transfer
- * in flight together (layers beyond the last one repeat it: no branches between the loads) */
-__device__ __forceinline__ void regs_store(const SwRegs& R, SwRow* __restrict__ rows, int nbr, int lane)
+/* ---- wave 0: the decode kernel of lnsfaid_kernel4.hip (messages streamed through HBM); every layered iteration is announced to
+ * wave 1 through the command word and run by both ---------------------------------------------------------- */
+template <int METHOD>
+__device__ __forceinline__ void decode5_wave0(const LfKernelArgs& a, unsigned char* smem, const int tid)
 {
-#pragma unroll
-    for (int br = 0; br < LF4_RM_LAYERS; ++br)
-        if (br < nbr) rows[br * LF_T4 + lane] = regs_get(R, br);
-}
-__device__ __forceinline__ void regs_load(SwRegs& R, const SwRow* __restrict__ rows, int nbr, int lane)
-{
-    SwRow r[LF4_RM_LAYERS];
-#pragma unroll
-    for (int br = 0; br < LF4_RM_LAYERS; ++br) r[br] = rows[(br < nbr ? br : nbr - 1) * LF_T4 + lane];
-#pragma unroll
-    for (int br = 0; br < LF4_RM_LAYERS; ++br) regs_put(R, br, r[br]);
-}
-__device__ __forceinline__ void regs_clear(SwRegs& R)
-{
-    const lf4_vec z = (lf4_vec)(0u);
-    R.x0 = z; R.x1 = z; R.x2 = z; R.cw = z; R.pa0 = z; R.pa1 = z;
-}
-
-/* ---- the decode kernel: one wave per codeword ---------------------------------------------------------- */
-template <int METHOD, bool RM, bool EF2>
-__global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs a)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
     CCode c = (CCode)a.code;
     CCfg f = (CCfg)a.cfg;
-    const int tid = (int)threadIdx.x;
     const int cw = (int)blockIdx.x;
     const int N = c->n_var, M = c->n_check, K = c->k_info, nw = c->n_words, pw = c->p_words;
     /* (the layer step addresses En by its LDS offset: the dynamic segment must start at 0, i.e. the kernel must have no static
@@ -235,8 +171,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
 
     bool in_bf = max_bf > 0 && prog >= t_bf0 && prog != 0;
     LfLaneState ls = { 0, 0, 0, 0 };
-    SwRegs R; /* RM: the codeword's compressed messages (dead in the bit-flipping stage) */
-    if (RM) regs_clear(R);
+    const uint32_t xch_base = lf_lds_off_hard(N);
 
     /* ---- bring the codeword's state on chip ---- */
     if (prog == 0) {
@@ -297,7 +232,6 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
         prog = 1;
     } else if (!in_bf) {
         copy_in<23>((uint32_t*)smem, g_en, N >> 2, tid);
-        if (RM && prog >= 2) regs_load(R, g_rows, c->nbr, tid); /* parked in front of iteration 1: every Lmn is still 0 */
         __syncthreads();
     } else {
         copy_in<9>(sHard, g_bits, nw, tid);
@@ -317,11 +251,6 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
              * kept alive - spilled, with the messages in registers - through every layer */
             int tid_i = tid;
             asm volatile("" : "+v"(tid_i));
-            if (METHOD == 0) { /* CLDPC::Decode has no syndrome stage and no early stop (CLDPC.cpp:287-2283) */
-                main_step4<METHOD, false, RM>(c, f, a.code, g_rows, R, tid_i, prog, sP, false, false, 0u);
-                prog++;
-                continue;
-            }
             bool lme = false, have_par = false;
             /* l_checksum_ and the unsatisfied count are consumed only inside the error-floor window
              * (nombre_iterations <= floor_iter_thresh: OMS selective offset CDecoder_OMS.cpp:388, 2B1C tables
@@ -333,7 +262,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
             if (must_know && (needs_checksums || !layer0_dirty4(c, tid_i))) {
                 build_plane4<false>(c, sHard, 0, tid_i);
                 int unsat;
-                if (RM || syn_cache_fits(c->nbr)) { /* (RM: a code of up to LF4_RM_LAYERS layers always fits) all table entries of the walk loaded together: one memory round trip, not one per round */
+                if (syn_cache_fits(c->nbr)) { /* all table entries of the walk loaded together: one memory round trip, not one per round */
                     SynCache sc;
                     syn_cache_load(a.code, c->nbr, tid_i, sc);
                     unsat = syndrome<LF_T4, false, true>(c, a.code, sP, tid_i, pA, pB, sRed, &sc);
@@ -344,7 +273,6 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
                 if (unsat == 0 && prog >= kmax && !group_passed(a.live, g, prog, tid_i)) {
                     /* the messages leave the registers here, not in the common epilogue: there the compiler would have to keep
                      * them alive through the whole bit-flipping stage */
-                    if (RM && prog >= 2) regs_store(R, g_rows, c->nbr, tid_i);
                     parked = true;
                     break;
                 }
@@ -353,13 +281,10 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
                 have_par = true;
             }
             publish_pass(a.live, cw, prog, tid_i);
-            if (EF2 && f->ef == 2 && needs_checksums && have_par && lme) {
-                /* EF_ELIMINATION 2 inside the window, few unsatisfied checks: this iteration erases (CDecoder_FAID.cpp:673-680) */
-                build_erasure_plane4(c, a.code, sHard, sP, f->W, tid_i);
-                main_step4<METHOD, EF2, RM>(c, f, a.code, g_rows, R, tid_i, prog, sP, true, lme, lf_lds_off_hard(N));
-            } else {
-                main_step4<METHOD, false, RM>(c, f, a.code, g_rows, R, tid_i, prog, sP, have_par && needs_checksums, lme, 0u);
-            }
+            /* hand the iteration to wave 1 (it sleeps at this barrier), then run wave 0's share of it */
+            if (tid_i == 0) sRed[LF5_CMD_SLOT] = prog;
+            lf5_barrier();
+            main_step5<METHOD, 0>(c, f, a.code, g_rows, tid_i, prog, sP, have_par && needs_checksums, lme, xch_base);
             prog++;
         }
         if (!parked && prog < t_end) {
@@ -386,7 +311,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
     /* ---- bit-flipping iterations.  Nothing of the layer step is alive here, so the lanes keep their entries of the walk
      * tables in registers for the whole stage (no table load, hence no exposed memory latency, per iteration) ---- */
     if (in_bf && !parked) {
-        if ((RM || syn_cache_fits(c->nbr)) && (METHOD == 3 || bf_cache_fits(c, f))) {
+        if (syn_cache_fits(c->nbr) && (METHOD == 3 || bf_cache_fits(c, f))) {
             SynCache sc;
             BfCache bc;
             syn_cache_load(a.code, c->nbr, tid, sc);
@@ -429,7 +354,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
          * (the syndrome stage has just built the plane from this En; in the bit-flipping stage the plane is the state) as the
          * output for the case that it stops here */
         if (!in_bf) {
-            copy_out<23>(g_en, (const uint32_t*)smem, N >> 2, tid); /* (RM: the messages were stored where the codeword parked) */
+            copy_out<23>(g_en, (const uint32_t*)smem, N >> 2, tid);
         } else {
             copy_out<9>(g_bits, sHard, nw, tid);
             copy_out<9>(g_bits + nw, sHard0, nw, tid);
@@ -441,29 +366,54 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
     }
 }
 
-/* Instances: messages in registers (RM) for codes of up to LF4_RM_LAYERS layers, streamed through HBM otherwise; the erasing
- * layer step of EF_ELIMINATION 2 (Decode_FAID only) lives in an instance of its own, so that the common ones do not carry its
- * registers. */
-extern "C" int lf_decode4_rm_layers(void) { return LF4_RM_LAYERS; }
-
-/* the instance a configuration runs on (for hipFuncGetAttributes / the occupancy query, and for the launch) */
-extern "C" const void* lf_decode4_func(int method, int ef, int rm)
+/* ---- the kernel: 128 threads per codeword ---- */
+template <int METHOD>
+__global__ __launch_bounds__(2 * LF_T4, 4) void lnsfaid_decode5_kernel(LfKernelArgs a)
 {
-    if (method == 2 && ef == 2) return (const void*)lnsfaid_decode4_kernel<2, false, true>;
-#define LF4_FUNC(M) case M: return rm ? (const void*)lnsfaid_decode4_kernel<M, true, false> : (const void*)lnsfaid_decode4_kernel<M, false, false>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    CCode c = (CCode)a.code;
+    const int N = c->n_var, nw = c->n_words, pw = c->p_words;
+    int* sRed = (int*)(smem + lf_lds_off_stat(N, nw, pw)) + LNSFAID_GROUP;
+    /* Fixed roles: the dispatcher already spreads the first and the second waves of the workgroups evenly over the four SIMDs of a CU
+     * (tools/ubench/hwid.hip: pairs (0,2) (1,3) (2,1) (3,0) in turn), so every SIMD holds two waves of either role.  (Swapping the
+     * roles by the parity of the wave slot skews that to 452 : 572 and costs 10 %: profiles/r03_two_waves/.) */
+    const int role = __builtin_amdgcn_readfirstlane(wave);
+    if (role == 0) {
+        decode5_wave0<METHOD>(a, smem, lane);
+        if (lane == 0) sRed[LF5_CMD_SLOT] = 0; /* every path of wave 0 ends here: wave 1 may go */
+        lf5_barrier();
+    } else {
+        CCfg f = (CCfg)a.cfg;
+        const int cw = (int)blockIdx.x;
+        SwRow* g_rows = (SwRow*)(a.st_rows + (size_t)cw * (size_t)(c->nbr * LF_T));
+        const uint32_t* sP = (const uint32_t*)(smem + lf_lds_off_p(N, nw));
+        for (;;) {
+            lf5_barrier();
+            const int it = __builtin_amdgcn_readfirstlane(sRed[LF5_CMD_SLOT]);
+            if (it == 0) break;
+            main_step5<METHOD, 1>(c, f, a.code, g_rows, lane, it, sP, false, false, lf_lds_off_hard(N));
+        }
+    }
+}
+
+extern "C" const void* lf_decode5_func(int method)
+{
     switch (method) {
-    case 0: return (const void*)lnsfaid_decode4_kernel<0, false, false>; /* (16-level search: with the messages in registers too the layer step spills) */
-        LF4_FUNC(1) LF4_FUNC(2) LF4_FUNC(3) LF4_FUNC(4) LF4_FUNC(5)
+    case 1: return (const void*)lnsfaid_decode5_kernel<1>;
+    case 2: return (const void*)lnsfaid_decode5_kernel<2>;
+    case 3: return (const void*)lnsfaid_decode5_kernel<3>;
+    case 4: return (const void*)lnsfaid_decode5_kernel<4>;
+    case 5: return (const void*)lnsfaid_decode5_kernel<5>;
     default: return nullptr;
     }
-#undef LF4_FUNC
 }
-extern "C" int lf_decode4_threads(void) { return LF_T4; }
+extern "C" int lf_decode5_threads(void) { return 2 * LF_T4; }
 
-extern "C" hipError_t lf_launch_decode4(int method, int ef, int rm, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream)
+extern "C" hipError_t lf_launch_decode5(int method, const LfKernelArgs* args, size_t lds_bytes, hipStream_t stream)
 {
-    const void* fn = lf_decode4_func(method, ef, rm);
+    const void* fn = lf_decode5_func(method);
     if (!fn) return hipErrorInvalidValue;
     void* kargs[] = { (void*)args };
-    return hipLaunchKernel(fn, dim3((unsigned)args->n_cw), dim3(LF_T4), kargs, lds_bytes, stream);
+    return hipLaunchKernel(fn, dim3((unsigned)args->n_cw), dim3(2 * LF_T4), kargs, lds_bytes, stream);
 }

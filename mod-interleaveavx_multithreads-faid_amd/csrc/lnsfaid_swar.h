@@ -346,10 +346,32 @@ SW_FN uint32_t sw_plane_bit(const SwLds& lds, uint32_t era_plane, uint32_t a)
  * rowpar: byte mask, 0xff in byte k if the syndrome bit of row i + 64 k is set (only read by the OMS selective offset
  * and the 2B1C error-floor tables); lme: unsat < floor_err_count for this codeword.
  * DecodeMethod 0 (NMS, one factor): the minimum search keeps 16 levels of |t| and maps them through cste() (sw_nms_tables). */
-template <int METHOD, int DEG, bool ERA = false, class Tab>
+/* Two waves per codeword (WAVES == 2, lnsfaid_kernel5.hip): the layer's edges are dealt to the two waves by the parity of their index,
+ * every lane of either wave still works on its four rows.  Wave 0 does everything that is per row (old arg-min patch, the merge of
+ * the two partial minimum searches, the new magnitudes, the arg-min edge, the row's record); wave 1 only passes 1 and 2 over its
+ * edges.  They meet four times per layer (xch.barrier()) and exchange through LDS (xch.put / xch.get, one dword per lane and slot):
+ *   A  wave 0 has patched the old arg-min nodes                                  -> both start pass 1
+ *   B  wave 1 has published its partial minima / index accumulators / sign XOR   -> wave 0 merges, finishes the row
+ *   C  wave 0 has READ the new arg-min nodes and published c2, F                  -> both start pass 2 (which overwrites the nodes)
+ *   D  wave 1 has written its En and published its sign bits                     -> wave 0 writes the exact arg-min En, the record
+ * SwNoXch: the single-wave build (every call compiles away). */
+#if SW_DEV
+#define SW_MFN __device__ __forceinline__
+#else
+#define SW_MFN inline
+#endif
+struct SwNoXch {
+    SW_MFN void put(int, uint32_t) const {}
+    SW_MFN uint32_t get(int) const { return 0u; }
+    SW_MFN void barrier() const {}
+};
+#define SW_OWN(j) (WAVES == 1 || (((j) & 1) == WAVE))
+
+template <int METHOD, int DEG, bool ERA = false, int WAVES = 1, int WAVE = 0, class Tab, class Xch = SwNoXch>
 SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, const SwK& K, uint32_t lane, int deg, SwRow cur, bool fresh,
-                          uint32_t rowpar, bool lme, uint32_t era_edges = 0u, uint32_t era_plane = 0u)
+                          uint32_t rowpar, bool lme, uint32_t era_edges = 0u, uint32_t era_plane = 0u, const Xch& xch = Xch())
 {
+    static_assert(WAVES == 1 || !ERA, "the erasing variant is built for one wave per codeword only");
     /* ERA (EF_ELIMINATION 2, CDecoder_FAID.cpp:673-680; the caller instantiates it only inside the error-floor window of a
      * codeword with few unsatisfied checks): era_edges bit j = edge j is the first edge, in row order, of a block column of
      * weight REGULAR_COL_WEIGHT; era_plane = LDS byte offset of a bit plane over the variable nodes, bit set = every check of
@@ -377,7 +399,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
     /* ---- the old arg-min edge carries c1, not c2: move its En by the difference so that "every edge carries c2" holds ---- */
     uint32_t padd = 0, psub = 0; /* what the patch below adds to / takes from the old arg-min nodes' LDS bytes */
 #ifndef SW_EXP_NO_OLDPATCH
-    if (!fresh) {
+    if (!fresh && WAVE == 0) {
         const uint32_t a0 = cur.pa[0] & 0xffffu, a1 = cur.pa[0] >> 16, a2 = cur.pa[1] & 0xffffu, a3 = cur.pa[1] >> 16;
         SW_SCHED_FENCE(); /* the four reads back to back: one LDS round trip, not one per read */
         const uint32_t g0 = lds.rd8(a0), g1 = lds.rd8(a1), g2 = lds.rd8(a2), g3 = lds.rd8(a3);
@@ -390,6 +412,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
         lds.wr8(a0, r); lds.wr8(a1, r >> 8); lds.wr8(a2, r >> 16); lds.wr8(a3, r >> 24);
     }
 #endif
+    if (WAVES == 2) xch.barrier(); /* A */
 
     SW_SCHED_FENCE();
     uint32_t tb[NJ], ts[NJ], ms[NJ], ad[NJ], rq[NJ], ld[NJ];
@@ -399,7 +422,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
     /* ---- pass 1 (CDecoder_FAID.cpp:662-861, CDecoder_OMS.cpp:363-380): all addresses, then all reads, then the arithmetic ---- */
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        if (DEG > 0 || j < deg) {
+        if ((DEG > 0 || j < deg) && SW_OWN(j)) {
             const uint32_t x4 = tid4 + s4j[j];
 #if SW_DEV
             uint32_t a;
@@ -412,7 +435,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-        if (DEG > 0 || j < deg) ld[j] = lds.rd32(ad[j]);
+        if ((DEG > 0 || j < deg) && SW_OWN(j)) ld[j] = lds.rd32(ad[j]);
     SW_SCHED_FENCE();
     /* The arithmetic of an edge is one long dependency chain and the hardware issues a wave's instructions in order, so the
      * statements below are written stage by stage over groups of SW_ILP edges: consecutive instructions then belong to
@@ -420,7 +443,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
 #pragma unroll
     for (int j0 = 0; j0 < NJ; j0 += SW_ILP) {
         uint32_t r_[SW_ILP], x_[SW_ILP], s_[SW_ILP], k_[SW_ILP], a_[SW_ILP], i_[SW_ILP], u_[SW_ILP];
-#define SW_EDGES(...) _Pragma("unroll") for (int g = 0; g < SW_ILP; ++g) { const int j = j0 + g; if (j < NJ && (DEG > 0 || j < deg)) { __VA_ARGS__ } }
+#define SW_EDGES(...) _Pragma("unroll") for (int g = 0; g < SW_ILP; ++g) { const int j = j0 + g; if (j < NJ && (DEG > 0 || j < deg) && SW_OWN(j)) { __VA_ARGS__ } }
         SW_EDGES(r_[g] = sw_alignbyte(ld[j], ld[j], rq[j]);)                                  /* byte k = En + 120 of row k */
         SW_EDGES(x_[g] = (j & 7) ? cur.x[j >> 3] >> (j & 7) : cur.x[j >> 3];)
         SW_EDGES(s_[g] = sw_bitop3<SW_TT_ANDOR>(x_[g], c01, c0642);)
@@ -469,10 +492,32 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
             SW_EDGES(u_[g] = sw_perm(tt_hi, tt_lo, a_[g]);)
         }
         SW_EDGES(
-            if (j & 1) sx = sw_bitop3<SW_TT_XOR3>(sx, ts[j - 1], ts[j]); else if (j == (DEG > 0 ? DEG : deg) - 1) sx ^= ts[j];
+            if (WAVES == 2) sx ^= ts[j]; /* (the neighbour edge belongs to the other wave) */
+            else if (j & 1) sx = sw_bitop3<SW_TT_XOR3>(sx, ts[j - 1], ts[j]); else if (j == (DEG > 0 ? DEG : deg) - 1) sx ^= ts[j];
             t2 = sw_bitop3<SW_TT_A_AND_BORC>(t2, t1, u_[g]);      /* VECTOR_MIN_2 with the old min1 */
             t1 &= u_[g];
             _Pragma("unroll") for (int b = 0; b < 5; ++b) if (((j >> b) & 1) == (b >= 3 ? 1 : 0)) ta[b] &= u_[g];)
+    }
+
+    if (WAVES == 2) {
+        /* index bit 0 is the wave: ta[0] (edges with the bit clear) is wave 0's own minimum */
+        if (WAVE == 1) {
+            xch.put(0, t1); xch.put(1, t2); xch.put(2, ta[1]); xch.put(3, ta[2]); xch.put(4, ta[3]); xch.put(5, ta[4]); xch.put(6, sx);
+        }
+        xch.barrier(); /* B */
+        if (WAVE == 0) {
+            const uint32_t o1 = xch.get(0), o2 = xch.get(1);
+            ta[0] = t1;
+            t2 = sw_bitop3<SW_TT_AND3>(t2, o2, t1 | o1); /* second minimum of the union: min(max(m1a, m1b), m2a, m2b) */
+            t1 &= o1;
+            ta[1] &= xch.get(2); ta[2] &= xch.get(3); ta[3] &= xch.get(4); ta[4] &= xch.get(5);
+            sx ^= xch.get(6);
+        }
+    }
+    uint32_t c2n_x = 0, fm_x = 0; /* what wave 1 takes over from wave 0 */
+    if (WAVES == 2 && WAVE == 1) {
+        xch.barrier(); /* C */
+        c2n_x = xch.get(0); fm_x = xch.get(1);
     }
 
     /* ---- the row's new magnitudes ---- */
@@ -503,7 +548,8 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
     /* new message on edge j is negative iff s_j ^ XOR_all(s) ^ (deg odd) (the 0xC0 / 0x40 constants of
      * CDecoder_FAID.cpp:902-917); with nn_j = bit 7 of ts_j = "V2C not negative" that is: not negative iff nn_j ^ F,
      * F = bit 7 of the XOR of all ts */
-    const uint32_t fm = sw_mask7(sx, sel_sign);
+    const uint32_t fm = (WAVES == 2 && WAVE == 1) ? fm_x : sw_mask7(sx, sel_sign);
+    if (WAVES == 2 && WAVE == 1) { c2n = c2n_x; c1n = 0u; } /* (everything per row below is wave 0's: dead code here) */
 
     /* ---- binary index of an edge that attains the minimum.  Bits 0..2: ta[b] runs over the edges whose index has bit b clear,
      * the bit is 1 iff none of them attains it.  Bits 3 and 4 the other way round (fewer edges have them set): ta[3] runs over
@@ -532,7 +578,7 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
 #ifdef SW_EXP_NO_ARGMIN /* timing experiment only: results are wrong */
     for (int k = 0; k < 4; ++k) sbk[k] = (cbj[k] << 16) | s4j[k];
 #else
-    for (int k = 0; k < 4; ++k) sbk[k] = tab.sb_dyn4((idx4 >> (8 * k)) & 0x7cu);
+    for (int k = 0; k < 4; ++k) sbk[k] = WAVE == 0 ? tab.sb_dyn4((idx4 >> (8 * k)) & 0x7cu) : 0u;
 #endif
     SW_SCHED_FENCE();
 
@@ -581,8 +627,12 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
 #ifdef SW_EXP_NO_ARGMIN
         gb |= (ld[k] & 0xffu) << (8 * k);
 #else
-        gb |= lds.rd8(pa[k]) << (8 * k);
+        if (WAVE == 0) gb |= lds.rd8(pa[k]) << (8 * k);
 #endif
+    }
+    if (WAVES == 2 && WAVE == 0) { /* the barrier also waits for the reads above: wave 1 may overwrite those nodes from here on */
+        xch.put(0, c2n); xch.put(1, fm);
+        xch.barrier(); /* C */
     }
     SW_SCHED_FENCE();
     SW_PASS2_STORE(0, en0)
@@ -627,7 +677,14 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
 #undef SW_EDGES
 #undef SW_PASS2_ARITH
 #undef SW_PASS2_STORE
-    /* the arg-min edge carries c1: its exact En replaces the as-if value pass 2 wrote (same lane, LDS operations in order) */
+    if (WAVES == 2) {
+        if (WAVE == 1) { xch.put(0, ns[0]); xch.put(1, ns[1]); xch.put(2, ns[2]); }
+        xch.barrier(); /* D: wave 1's En is in LDS */
+        if (WAVE == 1) { SwRow none = { { 0u, 0u, 0u }, 0u, { 0u, 0u } }; return none; }
+        ns[0] |= xch.get(0); ns[1] |= xch.get(1); ns[2] |= xch.get(2);
+    }
+    /* the arg-min edge carries c1: its exact En replaces the as-if value pass 2 wrote (same lane, LDS operations in order; with two
+     * waves: after barrier D, behind the other wave's as-if value) */
 #ifndef SW_EXP_NO_ARGMIN
 #pragma unroll
     for (int k = 0; k < 4; ++k) lds.wr8(pa[k], enA >> (8 * k));

@@ -87,6 +87,8 @@ SYMBOLS = {
     "lnsfaid_allreduce_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "lnsfaid_select_kernel": (C.c_int, [C.c_void_p, C.c_int32]),
     "lnsfaid_kernel_rows_per_lane": (C.c_int, [C.c_void_p]),
+    "lnsfaid_select_waves": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lnsfaid_kernel_waves": (C.c_int, [C.c_void_p]),
     "lnsfaid_select_message_store": (C.c_int, [C.c_void_p, C.c_int32]),
     "lnsfaid_message_store": (C.c_int, [C.c_void_p]),
     "lnsfaid_kernel_residency": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -216,6 +218,12 @@ class Decoder:
 
     def rows_per_lane(self):
         return self.lib.lnsfaid_kernel_rows_per_lane(self.ctx)
+
+    def select_waves(self, waves_per_codeword):
+        self._check(self.lib.lnsfaid_select_waves(self.ctx, waves_per_codeword), "lnsfaid_select_waves")
+
+    def kernel_waves(self):
+        return self.lib.lnsfaid_kernel_waves(self.ctx)
 
     def select_message_store(self, where):
         """0 default, MSG_REGISTERS, MSG_HBM (lnsfaid_select_message_store)"""

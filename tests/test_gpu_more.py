@@ -571,8 +571,12 @@ def test_ef_elimination_variants_of_decode_faid(abi, lib, code50, mode):
         with pytest.raises(RuntimeError):
             d.select_kernel(2)  # these variants exist in the four-rows-per-lane kernel only
         out, st = d.decode(fix, ng)
-        d.close()
         assert np.array_equal(out, ref) and np.array_equal(st, rst)
+        if mode == 1:  # the experimental two-waves-per-codeword kernel has the _ef tables too (not the erasure)
+            d.select_waves(2)
+            out, st = d.decode(fix, ng)
+            assert d.kernel_waves() == 2 and np.array_equal(out, ref) and np.array_equal(st, rst)
+        d.close()
     if mode == 2:  # the erasure changes what is decoded on the synthetic batch (else the test would prove nothing about it)
         cfg = abi.default_cfg(2, 6)
         assert lib.lnsfaid_cfg_ef_elimination(cfg, 2) == 0

@@ -177,6 +177,58 @@ def test_messages_in_registers_and_streamed_through_hbm_agree(abi, code50, metho
     assert np.array_equal(out_h, ref) and np.array_equal(st_h, ref_stats)
 
 
+@pytest.mark.parametrize("method", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("eb_n0", [3.55, 4.0, 3.0])
+def test_two_waves_per_codeword_agree(abi, code50, method, eb_n0):
+    """The experimental two-waves-per-codeword build of the four-rows kernel (lnsfaid_kernel5.hip: the edges of a layer dealt to
+    two wavefronts that exchange partial minima, sign products and the new magnitudes through LDS, four barriers per layer): the
+    same frames and iteration counts as the one-wave kernel and the oracle.  The 3.55 / 4.0 dB batches hold groups whose
+    codewords park and resume, 3.0 dB runs every layered and every bit-flipping iteration."""
+    cfg = abi.default_cfg(method, 10)
+    n = 6
+    fix = oa.ReferenceChannel(code50, 229, 13.0).groups(eb_n0, n)
+    ref, ref_stats = oa.Oracle(code50, cfg).decode(fix, n)
+    dec = abi.Decoder(code50, cfg, device=0, max_groups=n)
+    assert dec.kernel_waves() == 1
+    out1, st1 = dec.decode(fix, n)
+    dec.select_waves(2)
+    assert dec.kernel_waves() == 2 and dec.rows_per_lane() == 4 and dec.message_store() == abi.MSG_HBM
+    assert dec.kernel_residency() == (8, 8)  # 128 registers per wave: LDS still decides
+    out2, st2 = dec.decode(fix, n)
+    dec.select_waves(0)
+    assert dec.kernel_waves() == 1 and dec.message_store() == abi.MSG_REGISTERS
+    dec.close()
+    assert np.array_equal(out1, ref) and np.array_equal(st1, ref_stats)
+    assert np.array_equal(out2, ref) and np.array_equal(st2, ref_stats)
+
+
+def test_two_waves_per_codeword_selection_rules(abi, lib, code50):
+    """Refused where the kernel is not built: DecodeMethod 0, the erasing EF_ELIMINATION 2, configurations of the two-rows kernel."""
+    dec = abi.Decoder(code50, abi.default_cfg(0, 4), device=0, max_groups=1)
+    with pytest.raises(RuntimeError):
+        dec.select_waves(2)
+    dec.close()
+    cfg = abi.default_cfg(2, 10)
+    assert lib.lnsfaid_cfg_ef_elimination(cfg, 2) == 0
+    dec = abi.Decoder(code50, cfg, device=0, max_groups=1)
+    with pytest.raises(RuntimeError):
+        dec.select_waves(2)
+    dec.close()
+    cfg = abi.default_cfg(2, 10)
+    assert lib.lnsfaid_cfg_ef_elimination(cfg, 1) == 0
+    dec = abi.Decoder(code50, cfg, device=0, max_groups=1)
+    dec.select_waves(2)  # the _ef tables are a run-time switch of the same layer step
+    assert dec.kernel_waves() == 2
+    dec.close()
+    dec = abi.Decoder(code50, abi.default_cfg(1, 10), device=0, max_groups=1)
+    dec.select_kernel(2)
+    with pytest.raises(RuntimeError):
+        dec.select_waves(2)
+    with pytest.raises(RuntimeError):
+        dec.select_waves(3)
+    dec.close()
+
+
 def test_kernel_residency_is_what_the_lds_footprint_allows(abi, code50):
     """Eight codewords per CU for the 50G-PON code, for every kernel instance a shipped configuration selects: a build that loses
     residency to registers (or a static __shared__ in a decode kernel) fails here, not silently at 60 % of the throughput."""

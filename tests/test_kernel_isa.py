@@ -94,3 +94,39 @@ def test_layer_loop_waits_for_no_memory_but_the_prefetch(kernel4_asm):
                 n += 1
                 if "Depth=2" in info and "Header" in info and "s_waitcnt" in line and "vmcnt" in line:
                     assert n < 120, (name, n, line.strip())  # only in the short block that takes over the prefetched data
+
+
+@pytest.fixture(scope="module")
+def kernel5_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa5") / "kernel5.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S",
+                    "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "lnsfaid_kernel5.hip")], check=True, capture_output=True)
+    return out.read_text()
+
+
+def test_two_waves_per_codeword_kernel_fits_four_waves_per_simd(kernel5_asm):
+    # experimental lnsfaid_kernel5.hip: 128 registers per wave (8 codewords per CU x 2 waves = 4 waves per SIMD), no static LDS, and
+    # what the register budget spills stays outside the layer loops of both roles
+    parts = re.split(r"^(_Z\w+):", kernel5_asm, flags=re.M)
+    bodies = {parts[i]: parts[i + 1].split(".end_amdhsa_kernel")[0] for i in range(1, len(parts) - 1, 2) if "lnsfaid_decode5_kernel" in parts[i]}
+    assert len(bodies) == 5, sorted(bodies)
+    vgprs = [int(x) for x in re.findall(r"\.vgpr_count:\s*(\d+)", kernel5_asm)]
+    assert vgprs and max(vgprs) <= 128, vgprs
+    assert all(int(x) == 0 for x in re.findall(r"\.group_segment_fixed_size:\s*(\d+)", kernel5_asm))
+    for name, body in bodies.items():
+        info, big = "", []
+        for line in body.split("\n"):
+            m = re.match(r"^(\.LBB\d+_\d+):\s*;?(.*)", line)
+            if m:
+                big.append([m.group(2), []])
+            elif big and re.match(r"^\s+;.*(Loop|Depth)", line):
+                big[-1][0] += " " + line.strip()
+            elif big and re.match(r"^\s+[a-z]", line):
+                big[-1][1].append(line.strip())
+        layer_blocks = [b for b in big if "Depth=2" in b[0] and len(b[1]) > 300]
+        assert len(layer_blocks) >= 4, (name, len(layer_blocks))  # two per-degree instances of the layer step for either role
+        for info, ops in layer_blocks:
+            assert not [i for i in ops if i.startswith("scratch_")], (name, info)
+            assert sum(1 for i in ops if i.startswith("s_barrier")) >= 3, (name, info)
