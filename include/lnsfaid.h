@@ -196,8 +196,9 @@ int lnsfaid_count_errors_device(lnsfaid_ctx* ctx, const int8_t* d_decodedBits,
  *   sigma           CSimulate::Configure's sigma (CSimulate.cpp:69-74); the channel adds N(0, (sigma/sqrt 2)^2) per axis
  *   codeword        host, [n_var] bits 0/1 sent in every frame (FakeEncoder), NULL = all-zero
  *   d_fixInput      device, n_streams groups in the decoder's layout
- * Integer and float stages are bit-exact; Box-Muller uses the device's double log / cos, so single LLRs can
- * differ from the host generator's (rate bounded in tests/test_gpu_frontend.py).
+ * Integer and float stages are bit-exact; Box-Muller uses the device's double log / cos (directly, or as the arbiter of the
+ * single-precision fast path, see lnsfaid_frontend_set_exact), so single LLRs can differ from the host generator's (rate
+ * bounded in tests/test_gpu_frontend.py).
  */
 int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, const uint64_t* draws_before, size_t n_streams,
                             int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput);
@@ -207,6 +208,17 @@ int lnsfaid_frontend_device(lnsfaid_ctx* ctx, const uint32_t* seeds, const uint6
 int lnsfaid_frontend_device_states(lnsfaid_ctx* ctx, const uint32_t* states, const uint64_t* draws_before, size_t n_streams,
                                    int32_t mod_type, float sigma, float scale, const int8_t* codeword, int8_t* d_fixInput);
 uint64_t lnsfaid_frontend_draws_per_group(const lnsfaid_ctx* ctx, int32_t mod_type);
+
+/* The front-end kernel takes a quantised LLR from a single-precision evaluation of Box-Muller whenever no quantiser threshold
+ * lies within that evaluation's error bound, and recomputes the symbol in double precision otherwise (a few in ten thousand):
+ * same output, about a quarter of the time.  lnsfaid_frontend_set_exact(ctx, 1) (or LNSFAID_FRONTEND_EXACT=1 at creation)
+ * sends every symbol through the double-precision chain, written with the reference's own integer generator and float
+ * divisions - the A/B reference of the tests.
+ * lnsfaid_frontend_fastpath_bounds scans EVERY float u in [0, 1) on the device: measured[0] = max |sqrt(-2 ln(1 - u)) - fast|,
+ * measured[1] = max |cos(2 pi u) - fast|; assumed[] = what the kernel's bound uses.  measured must stay below assumed (the GPU
+ * test asserts a factor of two): run it once on a device whose transcendental units are not those of gfx950. */
+int lnsfaid_frontend_set_exact(lnsfaid_ctx* ctx, int32_t exact);
+int lnsfaid_frontend_fastpath_bounds(lnsfaid_ctx* ctx, double measured[2], double assumed[2]);
 
 /* Profile.txt InterleaveModType for lnsfaid_frontend_device: the block interleaver of BeforeModulationInterleaver /
  * AfterDeModulationDeInterleaver (CModulate.cpp:95-212) inside every frame; 1 (the default and the shipped value) is the

@@ -35,7 +35,9 @@ extern "C" hipError_t lf_launch_count_errors(const int8_t* decoded, const int8_t
 
 extern "C" hipError_t lf_launch_frontend(const uint32_t* d_seeds, const unsigned long long* d_draws, int n_streams, int mod_type,
                                          float sigma_ch, float scale, const int8_t* d_codeword, const int8_t* d_frames, int n_var,
-                                         int n_check, int interleave, int8_t* d_fix, hipStream_t stream);
+                                         int n_check, int interleave, int fast, int8_t* d_fix, hipStream_t stream);
+extern "C" hipError_t lf_frontend_fastpath_scan(double* d_out2, hipStream_t stream);
+extern "C" void lf_frontend_fastpath_assumed(double* eps2);
 
 #include <atomic>
 #include <chrono>
@@ -124,6 +126,7 @@ struct lnsfaid_ctx {
     int8_t* d_fe_input = nullptr;  /* their information bits, [stream][32][K] */
     size_t fe_frames_streams = 0;  /* 0: frames not in use */
     int fe_interleave = 1;         /* InterleaveModType of the device front-end */
+    int fe_exact = 0;              /* 1: every symbol through the double-precision chain (lnsfaid_frontend_set_exact) */
 };
 
 /* wait until everything queued on the context's stream so far has finished */
@@ -401,6 +404,8 @@ extern "C" int lnsfaid_create(lnsfaid_ctx** out, const lnsfaid_code* code, const
         ctx->rows_per_lane = (e[0] == '2') ? 2 : 0;
     if (const char* e = getenv("LNSFAID_WAVES_PER_CODEWORD")) /* test / A-B switch, see lnsfaid_select_waves */
         ctx->waves_per_cw = (e[0] == '2') ? 2 : 0;
+    if (const char* e = getenv("LNSFAID_FRONTEND_EXACT")) /* test / A-B switch, see lnsfaid_frontend_set_exact */
+        ctx->fe_exact = (e[0] == '1') ? 1 : 0;
     if (const char* e = getenv("LNSFAID_MSG_STORE")) /* test / A-B switch, see lnsfaid_select_message_store */
         ctx->msg_store = (e[0] == 'h') ? LNSFAID_MSG_HBM : ((e[0] == 'r') ? LNSFAID_MSG_REGISTERS : 0);
     g_live_contexts.fetch_add(1, std::memory_order_relaxed); /* (lnsfaid_destroy takes it back) */
@@ -1164,8 +1169,30 @@ extern "C" int lnsfaid_frontend_device_states(lnsfaid_ctx* ctx, const uint32_t* 
     HIP_TRY(lf_launch_frontend(ctx->d_fe_seeds, ctx->d_fe_draws, (int)n_streams, mod_type, sigma_ch, scale,
                                codeword ? ctx->d_fe_codeword : nullptr,
                                (!codeword && ctx->fe_frames_streams >= n_streams) ? ctx->d_fe_frames : nullptr, ctx->n_var,
-                               ctx->n_check, ctx->fe_interleave, d_fixInput, ctx->stream));
+                               ctx->n_check, ctx->fe_interleave, ctx->fe_exact ? 0 : 1, d_fixInput, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream)); /* states / draws_before may be reused by the caller */
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_frontend_set_exact(lnsfaid_ctx* ctx, int32_t exact)
+{
+    if (!ctx || exact < 0 || exact > 1) return LNSFAID_E_INVAL;
+    ctx->fe_exact = exact;
+    return LNSFAID_OK;
+}
+
+extern "C" int lnsfaid_frontend_fastpath_bounds(lnsfaid_ctx* ctx, double measured[2], double assumed[2])
+{
+    if (!ctx || !measured || !assumed) return LNSFAID_E_INVAL;
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* d = nullptr;
+    HIP_TRY(hipMalloc(&d, 2 * sizeof(double)));
+    hipError_t e = lf_frontend_fastpath_scan(d, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(measured, d, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    HIP_TRY(e);
+    lf_frontend_fastpath_assumed(assumed);
     return LNSFAID_OK;
 }
 

@@ -95,5 +95,7 @@ private:
     bool m_pinned = false;
     CEncoder m_encoder;
     bool m_encoder_ready = false;
+    bool m_fake_filled = false;            /* inputBits / outputBits hold FakeEncoder(m_fake_codeword) for every group */
+    const int* m_fake_codeword = nullptr;
 };
 #endif

@@ -88,6 +88,8 @@ SYMBOLS = {
     "lnsfaid_select_kernel": (C.c_int, [C.c_void_p, C.c_int32]),
     "lnsfaid_kernel_rows_per_lane": (C.c_int, [C.c_void_p]),
     "lnsfaid_select_waves": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lnsfaid_frontend_set_exact": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lnsfaid_frontend_fastpath_bounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lnsfaid_kernel_waves": (C.c_int, [C.c_void_p]),
     "lnsfaid_select_message_store": (C.c_int, [C.c_void_p, C.c_int32]),
     "lnsfaid_message_store": (C.c_int, [C.c_void_p]),

@@ -99,3 +99,41 @@ def test_device_frontend_higher_orders_and_interleaver(abi, lib, code50, encoder
     assert np.array_equal(ref.reshape(2, 32, N), np.stack(frames))
     assert lib.lnsfaid_frontend_set_interleave(dec.ctx, 7) != 0  # must divide the frame length
     dec.close()
+
+
+def test_fast_path_error_bounds_hold_for_every_float(abi, lib, code50):
+    """The single-precision Box-Muller of the front-end kernel decides a quantised LLR only when no threshold lies within its error
+    bound.  The bound rests on two constants - the largest distance of the hardware sqrt(-2 ln(1 - u)) and cos(2 pi u) from
+    double precision - which the library measures over EVERY float in [0, 1); the kernel assumes at least twice the measured."""
+    dec = abi.Decoder(code50, abi.default_cfg(2, 10), 0, 1)
+    measured, assumed = (C.c_double * 2)(), (C.c_double * 2)()
+    assert lib.lnsfaid_frontend_fastpath_bounds(dec.ctx, measured, assumed) == 0, lib.lnsfaid_last_hip_error()
+    dec.close()
+    print("front-end fast path: radius error %.3e (assumed %.1e), cosine error %.3e (assumed %.1e)" % (measured[0], assumed[0], measured[1], assumed[1]))
+    assert 0.0 < measured[0] * 2.0 <= assumed[0], (measured[0], assumed[0])
+    assert 0.0 < measured[1] * 2.0 <= assumed[1], (measured[1], assumed[1])
+
+
+@pytest.mark.parametrize("mod_type,scale,eb_n0,interleave", [(2, 13.0, 3.0, 1), (2, 13.0, 4.2, 1), (2, 7.3, 3.6, 1), (2, 13.0, 3.6, 3), (4, 12.5, 8.1, 1),
+                                                             (6, 13.0, 12.0, 2), (8, 13.0, 16.0, 1)])
+def test_fast_path_equals_the_double_precision_chain(abi, lib, code50, mod_type, scale, eb_n0, interleave):
+    """Fast path against lnsfaid_frontend_set_exact(1) - the reference's chain with its integer generator, IEEE float divisions
+    and double-precision log / cos / sqrt for every symbol - on 256 streams x 3 calls (434 M LLRs for QPSK): identical bytes."""
+    import torch
+    n = 256
+    dec = abi.Decoder(code50, abi.default_cfg(2, 10), 0, n)
+    assert lib.lnsfaid_frontend_set_interleave(dec.ctx, interleave) == 0
+    per_group = lib.lnsfaid_frontend_draws_per_group(dec.ctx, mod_type)
+    seeds = [101 + 2 * i for i in range(n)]
+    cw = np.unpackbits(np.fromfile(os.path.join(oa.ROOT, "tests", "golden", "codeword_50gpon.bin"), dtype=np.uint8))[:code50.N].astype(np.int8)
+    for call in range(3):
+        draws = [call * per_group + 4 * i for i in range(n)]  # (also draw counts that are not multiples of a group)
+        codeword = cw if call == 2 else None
+        assert lib.lnsfaid_frontend_set_exact(dec.ctx, 0) == 0
+        fast = _device_groups(abi, lib, dec, code50, seeds, draws, mod_type, eb_n0, scale, codeword)
+        assert lib.lnsfaid_frontend_set_exact(dec.ctx, 1) == 0
+        exact = _device_groups(abi, lib, dec, code50, seeds, draws, mod_type, eb_n0, scale, codeword)
+        assert int((fast != exact).sum().item()) == 0, (mod_type, call)
+        assert int((fast != 0).sum().item()) > fast.numel() // 2  # (not an all-zero buffer)
+    assert lib.lnsfaid_frontend_set_exact(dec.ctx, 2) != 0
+    dec.close()
