@@ -588,6 +588,23 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
     uint32_t cbit[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cbit[e] = K.cbit[e];
+    /* The two clamp tests of an edge, "over" = bit 7 of zb - oc and "not under" = bit 7 of zb, as select masks.  SW_CLAMP7: 0x7f
+     * masks from three full-rate operations each (b = x & 0x80.., b - (b >> 7)) instead of 0xff masks from a left shift and a
+     * v_perm_b32 (both half rate): enough here, because bit 7 is set in everything the selects choose between (zb where it is not
+     * under, 0x80 where it is, hi = 0xbe - c) */
+#ifdef SW_CLAMP7
+#define SW_CLAMP_MASKS(MO, MQ, OC, ZA)                                                                               \
+        SW_EDGES(MO[g] = OC[g] & c80;)                                                                               \
+        SW_EDGES(MQ[g] = ZA[g] & c80;)                                                                               \
+        SW_EDGES(MO[g] = MO[g] - (MO[g] >> 7);)                                                                      \
+        SW_EDGES(MQ[g] = MQ[g] - (MQ[g] >> 7);)
+#define SW_CLAMP_LOW(MQ, ZA) sw_bitop3<0xea>(ZA, MQ, c80) /* (a & b) | c */
+#else
+#define SW_CLAMP_MASKS(MO, MQ, OC, ZA)                                                                               \
+        SW_EDGES(MO[g] = sw_mask7(OC[g], sel_sign);)     /* over      */                                             \
+        SW_EDGES(MQ[g] = sw_mask7(ZA[g], sel_sign);)     /* not under */
+#define SW_CLAMP_LOW(MQ, ZA) sw_bitop3<SW_TT_SEL>(MQ, ZA, c80)
+#endif
     /* one group of edges: the arithmetic (ARITH) and the LDS writes (STORE) separately, stage by stage over the group as in pass 1 */
 #define SW_PASS2_ARITH(J0, EN)                                                                                       \
     {                                                                                                                \
@@ -599,9 +616,8 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
         SW_EDGES(hi[g] = MINSUM ? sw_bitop3<SW_TT_SEL>(ms[j], u2.hi[1], u2.hi[0]) : u2.hi[1];)                       \
         SW_EDGES(za[g] = tb[j] + za[g];)                 /* zb */                                                    \
         SW_EDGES(oc[g] = za[g] - oc[g];)                                                                             \
-        SW_EDGES(mo[g] = sw_mask7(oc[g], sel_sign);)     /* over      */                                             \
-        SW_EDGES(mq[g] = sw_mask7(za[g], sel_sign);)     /* not under */                                             \
-        SW_EDGES(EN[g] = sw_bitop3<SW_TT_SEL>(mq[g], za[g], c80);)                                                   \
+        SW_CLAMP_MASKS(mo, mq, oc, za)                                                                               \
+        SW_EDGES(EN[g] = SW_CLAMP_LOW(mq[g], za[g]);)                                                                \
         SW_EDGES(EN[g] = sw_bitop3<SW_TT_SEL>(mo[g], hi[g], EN[g]);)                                                 \
         SW_EDGES(EN[g] = EN[g] - sb[g];)                                                                             \
         SW_EDGES(EN[g] = sw_alignbyte(EN[g], EN[g], 4u - rq[j]);)                                                    \
@@ -677,6 +693,8 @@ SW_FN SwRow sw_layer_step(const SwLds& lds, const Tab& tab, const SwParams& p, c
 #undef SW_EDGES
 #undef SW_PASS2_ARITH
 #undef SW_PASS2_STORE
+#undef SW_CLAMP_MASKS
+#undef SW_CLAMP_LOW
     if (WAVES == 2) {
         if (WAVE == 1) { xch.put(0, ns[0]); xch.put(1, ns[1]); xch.put(2, ns[2]); }
         xch.barrier(); /* D: wave 1's En is in LDS */
