@@ -137,3 +137,26 @@ def test_fast_path_equals_the_double_precision_chain(abi, lib, code50, mod_type,
         assert int((fast != 0).sum().item()) > fast.numel() // 2  # (not an all-zero buffer)
     assert lib.lnsfaid_frontend_set_exact(dec.ctx, 2) != 0
     dec.close()
+
+
+def test_unaligned_output_buffer_takes_the_byte_store_path(abi, lib, code50):
+    """QPSK without interleaver writes 16 bytes per store when the output allows it; an output buffer that does not start on a
+    multiple of 16 gets the same bytes through single-byte stores."""
+    import torch
+    n = 8
+    dec = abi.Decoder(code50, abi.default_cfg(2, 10), 0, n)
+    seeds = (C.c_uint32 * n)(*[211 + 2 * i for i in range(n)])
+    draws = (C.c_uint64 * n)(*[0] * n)
+    sigma = oa.load().lnsfaid_frontend_sigma(3.6, 2, oa.ReferenceChannel.RATE)
+    size = n * 32 * code50.N
+    aligned = torch.zeros(size, dtype=torch.int8, device="cuda")
+    shifted = torch.zeros(size + 16, dtype=torch.int8, device="cuda")
+    assert aligned.data_ptr() % 16 == 0
+    assert lib.lnsfaid_frontend_device(dec.ctx, seeds, draws, n, 2, sigma, 13.0, None, aligned.data_ptr()) == 0
+    for off in (1, 4):
+        shifted.zero_()
+        assert lib.lnsfaid_frontend_device(dec.ctx, seeds, draws, n, 2, sigma, 13.0, None, shifted.data_ptr() + off) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(shifted[off:off + size], aligned)
+        assert int(shifted[:off].abs().sum().item()) == 0 and int(shifted[off + size:].abs().sum().item()) == 0
+    dec.close()

@@ -5,6 +5,7 @@ set -x
 REPO=$GRAFT_REPO_ROOT
 OUT=$REPO/gpurun_out/two_waves
 mkdir -p $OUT
+[ -x $REPO/tools/ubench/hwid ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -w -o $REPO/tools/ubench/hwid $REPO/tools/ubench/hwid.hip
 (cd $REPO && timeout -k 10 60 ./tools/ubench/hwid > $OUT/hwid.txt 2>&1)
 cd /tmp && export TMPDIR=/tmp
 export LNSFAID_WAVES_PER_CODEWORD=2
