@@ -481,7 +481,8 @@ extern "C" int lnsfaid_kernel_rows_per_lane(const lnsfaid_ctx* ctx) { return ctx
 static bool kernel5_possible(const lnsfaid_ctx* ctx)
 {
     const int m = ctx->hcfg.method;
-    return kernel4_possible(ctx) && m >= 1 && m <= 5 && !(m == 2 && ctx->hcfg.ef == 2);
+    /* (the two waves exchange 7 dwords per lane through the LDS of the hard-decision plane: n_words words) */
+    return kernel4_possible(ctx) && m >= 1 && m <= 5 && !(m == 2 && ctx->hcfg.ef == 2) && ctx->hcode.n_words >= 7 * 64;
 }
 static bool use_kernel5(const lnsfaid_ctx* ctx) { return ctx->waves_per_cw == 2 && use_kernel4(ctx) && kernel5_possible(ctx); }
 

@@ -431,6 +431,9 @@ def test_other_code_with_runtime_row_degree(abi, lib, method):
     ref, rst = oa.decode_mt(dc, cfg, fix, 3)
     d = abi.Decoder(dc, cfg, 0, 3)
     out, st = d.decode(fix, 3)
+    assert np.array_equal(out, ref) and np.array_equal(st, rst)
+    d.select_waves(2)  # the experimental two-waves-per-codeword kernel: its run-time-degree layer step, edges dealt by parity
+    out, st = d.decode(fix, 3)
     d.close()
     assert np.array_equal(out, ref) and np.array_equal(st, rst)
 
@@ -446,6 +449,9 @@ def test_other_code_with_low_row_degrees(abi, lib, method):
     ref, rst = oa.decode_mt(dc, cfg, fix, 3)
     d = abi.Decoder(dc, cfg, 0, 3)
     assert d.rows_per_lane() == 4
+    out, st = d.decode(fix, 3)
+    assert np.array_equal(out, ref) and np.array_equal(st, rst)
+    d.select_waves(2)  # rows of 3 edges: one wave of the pair has a single edge of them, index accumulators of either stay untouched
     out, st = d.decode(fix, 3)
     d.close()
     assert np.array_equal(out, ref) and np.array_equal(st, rst)
