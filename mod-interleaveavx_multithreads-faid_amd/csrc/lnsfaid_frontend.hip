@@ -215,6 +215,9 @@ __global__ __launch_bounds__(256) void lnsfaid_frontend_kernel(const uint32_t* _
      * start on a multiple of 2 FE_RUN (K, M and N are), so they leave as 16-byte stores, one per 8 symbols, instead of single bytes */
     const bool packed = Q == 2 && I == 1 && (K % (2 * FE_RUN)) == 0 && (N % (2 * FE_RUN)) == 0 && last - first == FE_RUN && ((size_t)out % 16) == 0;
     const uint32_t out0 = fp < K ? fm * K + fp : 32u * K + fm * M + (fp - K);
+    /* higher orders without interleaver: the Q LLRs of a symbol are consecutive bytes of one frame part when Q divides K and N,
+     * and leave as one 4- / 8-byte store (three 2-byte stores for 64-QAM) */
+    const bool wide = Q > 2 && I == 1 && (K % Q) == 0 && (N % Q) == 0 && ((size_t)out % 8) == 0;
     uint32_t pack[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll 1
     for (uint32_t i = first; i < last; ++i) {
@@ -280,6 +283,14 @@ __global__ __launch_bounds__(256) void lnsfaid_frontend_kernel(const uint32_t* _
                 *(uint4*)(out + out0 + 2u * (k - 7u)) = make_uint4(pack[0], pack[1], pack[2], pack[3]);
                 pack[0] = pack[1] = pack[2] = pack[3] = 0u;
             }
+        } else if (wide) {
+            uint32_t w[2] = { 0u, 0u };
+#pragma unroll
+            for (uint32_t u = 0; u < Q; ++u) w[u / 4] |= (uint32_t)(uint8_t)quantise_4bit(l[u], scale) << (8 * (u % 4));
+            int8_t* dst = out + cidx[0];
+            if (Q == 4) *(uint32_t*)dst = w[0];
+            else if (Q == 8) *(uint2*)dst = make_uint2(w[0], w[1]);
+            else { *(uint16_t*)dst = (uint16_t)w[0]; *(uint16_t*)(dst + 2) = (uint16_t)(w[0] >> 16); *(uint16_t*)(dst + 4) = (uint16_t)w[1]; }
         } else {
 #pragma unroll
             for (uint32_t u = 0; u < Q; ++u) out[cidx[u]] = quantise_4bit(l[u], scale);

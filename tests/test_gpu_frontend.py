@@ -139,23 +139,24 @@ def test_fast_path_equals_the_double_precision_chain(abi, lib, code50, mod_type,
     dec.close()
 
 
-def test_unaligned_output_buffer_takes_the_byte_store_path(abi, lib, code50):
-    """QPSK without interleaver writes 16 bytes per store when the output allows it; an output buffer that does not start on a
-    multiple of 16 gets the same bytes through single-byte stores."""
+@pytest.mark.parametrize("mod_type,scale,eb_n0", [(2, 13.0, 3.6), (4, 12.5, 8.1), (6, 13.0, 12.0)])
+def test_unaligned_output_buffer_takes_the_byte_store_path(abi, lib, code50, mod_type, scale, eb_n0):
+    """Without interleaver the kernel writes 16 bytes per store (QPSK) or one symbol per store (higher orders) when the output
+    allows it; an output buffer that does not start on a multiple of 16 gets the same bytes through single-byte stores."""
     import torch
     n = 8
     dec = abi.Decoder(code50, abi.default_cfg(2, 10), 0, n)
     seeds = (C.c_uint32 * n)(*[211 + 2 * i for i in range(n)])
     draws = (C.c_uint64 * n)(*[0] * n)
-    sigma = oa.load().lnsfaid_frontend_sigma(3.6, 2, oa.ReferenceChannel.RATE)
+    sigma = oa.load().lnsfaid_frontend_sigma(eb_n0, mod_type, oa.ReferenceChannel.RATE)
     size = n * 32 * code50.N
     aligned = torch.zeros(size, dtype=torch.int8, device="cuda")
     shifted = torch.zeros(size + 16, dtype=torch.int8, device="cuda")
     assert aligned.data_ptr() % 16 == 0
-    assert lib.lnsfaid_frontend_device(dec.ctx, seeds, draws, n, 2, sigma, 13.0, None, aligned.data_ptr()) == 0
+    assert lib.lnsfaid_frontend_device(dec.ctx, seeds, draws, n, mod_type, sigma, scale, None, aligned.data_ptr()) == 0
     for off in (1, 4):
         shifted.zero_()
-        assert lib.lnsfaid_frontend_device(dec.ctx, seeds, draws, n, 2, sigma, 13.0, None, shifted.data_ptr() + off) == 0
+        assert lib.lnsfaid_frontend_device(dec.ctx, seeds, draws, n, mod_type, sigma, scale, None, shifted.data_ptr() + off) == 0
         torch.cuda.synchronize()
         assert torch.equal(shifted[off:off + size], aligned)
         assert int(shifted[:off].abs().sum().item()) == 0 and int(shifted[off + size:].abs().sum().item()) == 0
