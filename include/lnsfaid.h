@@ -161,6 +161,7 @@ int lnsfaid_decode(lnsfaid_ctx* ctx, const int8_t* fixInput, size_t n_groups,
  * created with max_groups == 1 on the same device and for the same code are decoded in common launches (from four such
  * contexts on; results bit-identical to separate launches; the call still returns only when its own group is done).
  * Environment: LNSFAID_COALESCE=0 switches it off, LNSFAID_COMB_WORKERS (1..4, default 2) sets the batches in flight,
+ * LNSFAID_COMB_BATCHES (default: the number of workers) into how many batches the members' calls are cut,
  * LNSFAID_SYNC=spin|block overrides how the host waits for the GPU (default: sleep from five live contexts on). */
 
 /* Same with device-resident buffers (pointers valid on the context's GPU).  Work is queued on the context's stream; the

@@ -736,6 +736,18 @@ static int comb_workers()
     return n;
 }
 
+/* into how many batches the members' calls are cut (>= the number of workers; LNSFAID_COMB_BATCHES): more, smaller batches than
+ * workers keep the launches out of phase - a worker that comes back from the device finds the next batch waiting */
+static int comb_batches()
+{
+    static const int v = [] {
+        const char* e = getenv("LNSFAID_COMB_BATCHES");
+        const int n = e ? atoi(e) : 0;
+        return n > 64 ? 64 : n;
+    }();
+    return v > comb_workers() ? v : comb_workers();
+}
+
 static bool comb_enabled()
 {
     static const char* e = getenv("LNSFAID_COALESCE");
@@ -808,7 +820,7 @@ static void comb_worker(LfCombiner* cb, int w)
         const auto t_first = std::chrono::steady_clock::now();
         const auto deadline = t_first + std::chrono::microseconds(LF_COMB_WINDOW_US);
         for (;;) {
-            const int share = (cb->members + comb_workers() - 1) / comb_workers();
+            const int share = (cb->members + comb_batches() - 1) / comb_batches();
             if (cb->stop || cb->pending >= share || cb->pending + cb->running >= cb->members) break;
             const int seen = cb->pending, seen_running = cb->running;
             auto quiet = std::chrono::steady_clock::now() + std::chrono::microseconds(LF_COMB_QUIET_US);
@@ -819,7 +831,7 @@ static void comb_worker(LfCombiner* cb, int w)
         if (cb->stop) { cb->gathering = false; break; }
         cb->gather_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_first).count();
         int batch[LF_COMB_SLOTS], nb = 0;
-        const int cap = cb->members > 8 * comb_workers() ? (cb->members + comb_workers() - 1) / comb_workers() : LF_COMB_SLOTS;
+        const int cap = cb->members > 8 * comb_workers() ? (cb->members + comb_batches() - 1) / comb_batches() : LF_COMB_SLOTS;
         const LfDevCfg* cfg = nullptr; /* one configuration per batch: the first pending one's */
         for (int i = 0; i < LF_COMB_SLOTS && nb < cap; ++i) {
             LfSlot& s = cb->slots[i];
