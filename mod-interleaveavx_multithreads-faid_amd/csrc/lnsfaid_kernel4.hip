@@ -204,7 +204,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
         kmax = __builtin_amdgcn_readlane(v, 31);
     }
     const int all_same = __ballot(sv != my_status) == 0ull;
-    __syncthreads();
+    LF_WG_SYNC();
     int prog = my_status & LF_PROG_MASK;
 
     uint32_t* g_en = (uint32_t*)(a.st_en + (size_t)cw * (size_t)N);
@@ -293,18 +293,18 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
                 lds4_wr((uint32_t)cb * 256u + 4u * (uint32_t)tid, w);
             }
         }
-        __syncthreads();
+        LF_WG_SYNC();
         prog = 1;
     } else if (!in_bf) {
         copy_in<23>((uint32_t*)smem, g_en, N >> 2, tid);
         if (RM && prog >= 2) regs_load(R, g_rows, c->nbr, tid); /* parked in front of iteration 1: every Lmn is still 0 */
-        __syncthreads();
+        LF_WG_SYNC();
     } else {
         copy_in<9>(sHard, g_bits, nw, tid);
         copy_in<9>(sHard0, g_bits + nw, nw, tid);
         copy_in<9>(sHard2, g_bits + 2 * nw, nw, tid);
         ls = a.st_lane[cw];
-        __syncthreads();
+        LF_WG_SYNC();
     }
 
     bool parked = false;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
                 build_plane4<true>(c, sHard, f->hard2_thr, tid); /* staged where the hard plane will go */
 #pragma unroll
                 for (int k = 0; k < LF_MAX_BC * 8 / LF_T4; ++k) conf[k] = (tid + k * LF_T4 < nw) ? sHard[tid + k * LF_T4] : 0u;
-                __syncthreads();
+                LF_WG_SYNC();
             }
             build_plane4<false>(c, sHard, 0, tid);
             /* En is dead from here on: its bytes take hard_ch (= hard) and hard2 */
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(LF_T4, 2) void lnsfaid_decode4_kernel(LfKernelArgs 
             }
             ls.Th = (int8_t)f->W; ls.l0 = 0; ls.l1 = 0; ls.t = 1;
             in_bf = true;
-            __syncthreads();
+            LF_WG_SYNC();
         }
     }
     /* ---- bit-flipping iterations.  Nothing of the layer step is alive here, so the lanes keep their entries of the walk

@@ -13,14 +13,14 @@
  */
 #include <hip/hip_runtime.h>
 
-/* Wave 0 runs the single-wave phases of lnsfaid_kernel4.hip / lnsfaid_phases.h on its own: their __syncthreads() (a no-op
- * barrier plus an LDS fence in a one-wave workgroup) must not become an s_barrier that waits for wave 1. */
+/* Wave 0 runs the single-wave phases of lnsfaid_kernel4.hip / lnsfaid_phases.h on its own: their LF_WG_SYNC() (__syncthreads():
+ * a no-op barrier plus an LDS fence in a one-wave workgroup) must not become an s_barrier that waits for wave 1. */
 __device__ __forceinline__ void lf5_wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
-#define __syncthreads() lf5_wave_sync()
+#define LF_WG_SYNC() lf5_wave_sync()
 /* both waves of the workgroup */
 __device__ __forceinline__ void lf5_barrier()
 {
@@ -140,7 +140,7 @@ __device__ __forceinline__ void decode5_wave0(const LfKernelArgs& a, unsigned ch
         kmax = __builtin_amdgcn_readlane(v, 31);
     }
     const int all_same = __ballot(sv != my_status) == 0ull;
-    __syncthreads();
+    LF_WG_SYNC();
     int prog = my_status & LF_PROG_MASK;
 
     uint32_t* g_en = (uint32_t*)(a.st_en + (size_t)cw * (size_t)N);
@@ -228,17 +228,17 @@ __device__ __forceinline__ void decode5_wave0(const LfKernelArgs& a, unsigned ch
                 lds4_wr((uint32_t)cb * 256u + 4u * (uint32_t)tid, w);
             }
         }
-        __syncthreads();
+        LF_WG_SYNC();
         prog = 1;
     } else if (!in_bf) {
         copy_in<23>((uint32_t*)smem, g_en, N >> 2, tid);
-        __syncthreads();
+        LF_WG_SYNC();
     } else {
         copy_in<9>(sHard, g_bits, nw, tid);
         copy_in<9>(sHard0, g_bits + nw, nw, tid);
         copy_in<9>(sHard2, g_bits + 2 * nw, nw, tid);
         ls = a.st_lane[cw];
-        __syncthreads();
+        LF_WG_SYNC();
     }
 
     bool parked = false;
@@ -294,7 +294,7 @@ __device__ __forceinline__ void decode5_wave0(const LfKernelArgs& a, unsigned ch
                 build_plane4<true>(c, sHard, f->hard2_thr, tid); /* staged where the hard plane will go */
 #pragma unroll
                 for (int k = 0; k < LF_MAX_BC * 8 / LF_T4; ++k) conf[k] = (tid + k * LF_T4 < nw) ? sHard[tid + k * LF_T4] : 0u;
-                __syncthreads();
+                LF_WG_SYNC();
             }
             build_plane4<false>(c, sHard, 0, tid);
             /* En is dead from here on: its bytes take hard_ch (= hard) and hard2 */
@@ -305,7 +305,7 @@ __device__ __forceinline__ void decode5_wave0(const LfKernelArgs& a, unsigned ch
             }
             ls.Th = (int8_t)f->W; ls.l0 = 0; ls.l1 = 0; ls.t = 1;
             in_bf = true;
-            __syncthreads();
+            LF_WG_SYNC();
         }
     }
     /* ---- bit-flipping iterations.  Nothing of the layer step is alive here, so the lanes keep their entries of the walk

@@ -7,6 +7,13 @@
 #ifndef LNSFAID_PHASES_H
 #define LNSFAID_PHASES_H
 
+/* Workgroup-wide synchronisation of the phases below and of the kernels that include them.  A kernel whose workgroup holds a wave
+ * that does not take part in these phases (lnsfaid_kernel5.hip: its second wave sleeps at a barrier meanwhile) defines it
+ * before including this header as the fence its working wave needs instead. */
+#ifndef LF_WG_SYNC
+#define LF_WG_SYNC() __syncthreads()
+#endif
+
 #include <hip/hip_runtime.h>
 
 #include "lnsfaid_device.h"
@@ -23,14 +30,14 @@ template <int T>
 __device__ __forceinline__ int block_sum(int wave_value, int tid, int* sRed)
 {
     if (T == 64) {
-        __syncthreads(); /* one wave: nothing to add up, LDS operations of a wave execute in order */
+        LF_WG_SYNC(); /* one wave: nothing to add up, LDS operations of a wave execute in order */
         return wave_value;
     }
     if ((tid & 63) == 0) sRed[tid >> 6] = wave_value;
-    __syncthreads();
+    LF_WG_SYNC();
     int total = 0;
     for (int w = 0; w < T / 64; ++w) total += sRed[w];
-    __syncthreads();
+    LF_WG_SYNC();
     return total;
 }
 
@@ -332,11 +339,11 @@ __device__ __forceinline__ void bf_step_plain(CCode c, CCfg f, const LfDevCode* 
     for (int o = 32; o > 0; o >>= 1) seen |= (uint32_t)__shfl_xor((int)seen, o);
     if (T > 64) {
         if ((tid & 63) == 0) sRed[tid >> 6] = (int)seen;
-        __syncthreads();
+        LF_WG_SYNC();
         seen = 0;
         for (int w = 0; w < T / 64; ++w) seen |= (uint32_t)sRed[w];
     }
-    __syncthreads();
+    LF_WG_SYNC();
     const int max_vote = seen ? 31 - __clz((int)seen) : 1; /* max_vote starts at 1 (CDecoder_OMSBF.cpp:2975) */
     const int thr = imin(imax(max_vote, 1), (int)(int8_t)f->vote_cap);
     for (int u = tid; u < units; u += T) {
@@ -349,7 +356,7 @@ __device__ __forceinline__ void bf_step_plain(CCode c, CCfg f, const LfDevCode* 
             sHard[w0 + h] ^= m;
         }
     }
-    __syncthreads();
+    LF_WG_SYNC();
 }
 
 #endif /* LNSFAID_PHASES_H */

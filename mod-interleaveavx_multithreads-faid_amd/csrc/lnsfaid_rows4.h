@@ -2,7 +2,7 @@
  * lnsfaid_rows4.h - what the four-rows-per-lane decode kernels share outside the layer step: the code-table view the layer step
  * reads, staging copies, the hard-decision / confidence bit planes, the live-progress words, output staging, the erasure plane of
  * EF_ELIMINATION 2.  Included by lnsfaid_kernel4.hip (one wave per codeword) and lnsfaid_kernel5.hip (two waves per codeword, where
- * __syncthreads() is redefined to the one-wave fence before this header is read: everything here runs on ONE wave).
+ * LF_WG_SYNC() is redefined to the one-wave fence before this header is read: everything here runs on ONE wave).
  */
 #ifndef LNSFAID_ROWS4_H
 #define LNSFAID_ROWS4_H
@@ -119,7 +119,7 @@ __device__ __forceinline__ void build_plane4(CCode c, uint32_t* plane, int thr, 
         g = plane_exchange<1>(g, l5);
         if (cb0 + (int)(l5 & 7u) < nbc) plane[cb0 * 8 + word_of_lane] = g;
     }
-    __syncthreads();
+    LF_WG_SYNC();
 }
 
 /* ---- cheap "certainly dirty" test (DecodeMethod 2, see lnsfaid_kernels.hip): parity of the lane's four rows of layer 0
@@ -220,7 +220,7 @@ __device__ void build_erasure_plane4(CCode c, const LfDevCode* gc, uint32_t* pla
         plane[cb * 8 + 2 * (int)win] = lo;
         plane[cb * 8 + 2 * (int)win + 1] = hi;
     }
-    __syncthreads();
+    LF_WG_SYNC();
 }
 
 #endif /* LNSFAID_ROWS4_H */
