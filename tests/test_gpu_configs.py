@@ -62,10 +62,10 @@ def test_config1_bpsk_oms_through_the_driver(abi, code50, tmp_path):
 
 def test_config3_fer_sweep_with_the_reference_stop_rule(abi, code50, tmp_path):
     """DecodeMethod 2, Eb/N0 3.3 ... 3.8 step 0.1, 4 streams (reference threads 0..3): every point runs rounds of 50 calls per
-    stream until TestFrame >= 1000 and ErrorFrame >= 20 (reference main.cpp:164, :209), capped at 3 rounds where the error
+    stream until TestFrame >= 1000 and ErrorFrame >= 20 (reference main.cpp:164, :209), capped at 2 rounds where the error
     rate is too low for that; counters of every point, as printed and as appended to Result.txt, against the CPU port fed by
     the restated reference channel (whose generators run on across the points exactly like the driver's)."""
-    streams, cap = 4, 3
+    streams, cap = 4, 2
     _profile(tmp_path, 3.3, 3.85, method=2)
     res = subprocess.run([EXE, "--streams", str(streams), "--max-rounds", str(cap)], cwd=tmp_path, capture_output=True, text=True,
                          timeout=1500)

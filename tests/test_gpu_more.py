@@ -513,10 +513,10 @@ def test_random_codewords(abi, code50, encoder, method, eb_n0):
 @pytest.mark.parametrize("eb_n0", [3.2, 3.6, 4.0])
 @pytest.mark.parametrize("method", [2, 5, 1, 0, -1, 4, 3])
 def test_soak_against_cpu_port(abi, code50, method, eb_n0):
-    """32 768 frames per case (1024 groups, several dispatch rounds of workgroups) against the vectorised CPU port, every
+    """16 384 frames per case (512 groups, eight dispatch rounds of workgroups) against the vectorised CPU port, every
     frame and every per-group iteration count: the place where rare message patterns (ties, zero messages on the argmin
-    edge, saturated rows) turn up."""
-    ng = 1024
+    edge, saturated rows) turn up.  (tools/gpu_soak.py is the long version: 65 536 frames per case, every kernel variant.)"""
+    ng = 512
     uni = method == -1  # DecodeMethod 0 with one normalisation factor: the kernel's patch path
     method = 0 if uni else method
     cfg = abi.default_cfg(method, 10)
